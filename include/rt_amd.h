@@ -1,0 +1,187 @@
+/*
+ * rt_amd.h -- C ABI of the MI355X (gfx950) Monte Carlo dust photon random walk.
+ *
+ * This is the drop-in boundary for ONE hot path of ianblackstone/Radiative-Transfer:
+ * the photon random walk `RunPhotons` and the atmosphere sweep that calls it.
+ * The reference has no FFI layer of its own; its boundary is two Python call
+ * signatures, and every entry point below names the reference interface it
+ * replaces (file:line into the reference checkout).  The thin Python host in
+ * radiative-transfer_amd/ binds these with ctypes and re-creates the Python
+ * signatures on top.
+ *
+ * Conventions
+ *   - plain C types only; all array arguments are caller-owned HOST buffers
+ *     unless a name starts with d_ (device pointer of the context's GPU);
+ *   - every function returns 0 on success or a negative rt_status; the text of
+ *     the last failure on the calling thread is returned by rt_last_error();
+ *   - a context is bound to one GPU and is not thread-safe; use one context
+ *     per host thread / per process rank;
+ *   - there is no CPU fallback: if no gfx950 device is usable rt_create fails.
+ */
+#ifndef RT_AMD_H
+#define RT_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_ABI_VERSION 1
+
+typedef enum rt_status {
+    RT_OK = 0,
+    RT_ERR_INVALID = -1, /* bad argument */
+    RT_ERR_DEVICE = -2,  /* HIP runtime / no device */
+    RT_ERR_STATE = -3,   /* call order (e.g. run before tables) */
+    RT_ERR_LIMIT = -4    /* size beyond a documented maximum */
+} rt_status;
+
+/* boundary condition of the lower face, MC code.py:522-574 */
+enum { RT_BOUNDARY_REFLECT = 0, RT_BOUNDARY_ABSORB = 1, RT_BOUNDARY_REEMIT = 2 };
+/* scattering law, MC code.py:732-760 and Numpy_random_walk.py:369-396 */
+enum { RT_SCATTER_HG = 0, RT_SCATTER_ISO = 1, RT_SCATTER_DRAINE = 2 };
+/* order of the tests inside one loop iteration:
+ *   RT_ORDER_MC    step, escape(tallied), boundary, escape(logged), absorb, scatter  (MC code.py:657-767)
+ *   RT_ORDER_GRAY  step, boundary, escape(tallied+logged), absorb, scatter           (Numpy_random_walk.py:313-396)
+ * RT_ORDER_GRAY also weights momentum by lambda instead of 1/lambda (Numpy_random_walk.py:55). */
+enum { RT_ORDER_MC = 0, RT_ORDER_GRAY = 1 };
+
+/* per-photon fates reported by rt_replay */
+enum {
+    RT_FATE_ESCAPED = 1,           /* left through the top, momentum tallied */
+    RT_FATE_ESCAPED_UNCOUNTED = 2, /* removed by the second escape test of RT_ORDER_MC (MC code.py:690) */
+    RT_FATE_ABSORBED = 3,          /* absorbed by dust (MC code.py:479) */
+    RT_FATE_BOUNDARY = 4,          /* absorbed by the lower boundary (MC code.py:551-556) */
+    RT_FATE_GUARD = 5              /* max_events_per_photon reached; the reference would loop forever */
+};
+
+/* Floating-point tallies per atmosphere: sums[atm * RT_NSUM + k].
+ * p = mu * w * h is a photon's z momentum, w = 1/lambda (RT_ORDER_MC) or lambda (RT_ORDER_GRAY),
+ * as in GetZMomentum (MC code.py:360-369). */
+enum {
+    RT_SUM_INITIAL = 0,           /* initial_momentum,  MC code.py:642 */
+    RT_SUM_ESCAPED = 1,           /* escaped_momentum,  MC code.py:670 (first test only) */
+    RT_SUM_BOUNDARY = 2,          /* boundary_momentum, MC code.py:541,553,561 (reference signs) */
+    RT_SUM_ESCAPED_UNCOUNTED = 3, /* momentum the reference drops at MC code.py:690 */
+    RT_SUM_TRANSFER_SQ = 4,       /* sum_i t_i^2,  t_i = p0_i - escaped_i + boundary_i of photon i */
+    RT_SUM_TRANSFER_P0 = 5,       /* sum_i t_i * p0_i */
+    RT_SUM_P0_SQ = 6,             /* sum_i p0_i^2 */
+    RT_SUM_ABSORBED_ENERGY = 7,   /* sum of w*h over dust-absorbed photons */
+    RT_SUM_DUST_MOMENTUM = 8,     /* sum over collisions of (p_before - p_after); the reference's
+                                     commented-out second estimator, MC code.py:648-650,728-729,773-776 */
+    RT_SUM_REEMITTED = 9,         /* momentum of photons re-emitted at the boundary (RT_BOUNDARY_REEMIT) */
+    RT_NSUM = 10
+};
+
+/* Integer tallies per atmosphere: counts[atm * RT_NCNT + k]. */
+enum {
+    RT_CNT_SCATTER = 0,           /* scatter_count, MC code.py:767 -- the throughput metric's event */
+    RT_CNT_ESCAPED = 1,
+    RT_CNT_ESCAPED_UNCOUNTED = 2,
+    RT_CNT_ABSORBED = 3,
+    RT_CNT_BOUNDARY_ABSORBED = 4,
+    RT_CNT_REEMITTED = 5,
+    RT_CNT_GUARD = 6,
+    RT_CNT_PHOTONS = 7,           /* photon histories started */
+    RT_CNT_FLIGHTS = 8,           /* loop iterations summed over photons (one TakeStep each) */
+    RT_CNT_BOUNDARY_HITS = 9,     /* z <= 0 events */
+    RT_NCNT = 10
+};
+
+/* One sweep over n_atm atmospheres (the loop of runMC, MC code.py:1056-1062). */
+typedef struct rt_params {
+    int32_t n_atm;
+    int32_t boundary;              /* RT_BOUNDARY_* ; reference flag `boundary`, MC code.py:78 */
+    int32_t scatter;               /* RT_SCATTER_*  ; reference flag `scatter`,  MC code.py:81 */
+    int32_t loop_order;            /* RT_ORDER_* */
+    int32_t rand_mu;               /* reference global `rand_mu`,  MC code.py:84, :384-385 */
+    int32_t abs_only;              /* reference global `abs_only`, MC code.py:85, :478-481 */
+    int32_t n_mu_bins;             /* escape-cosine histogram bins (0..1), plus one overflow bin for mu >= 1 */
+    int32_t n_depth_bins;          /* depth-resolved deposition bins (extension; 0 = off) */
+    int32_t max_events_per_photon; /* iteration guard per photon; <= 0 selects 1<<20 */
+    int32_t n_slabs;               /* fixed partition of every atmosphere's photon-id range (default 8) */
+    int32_t rank;                  /* this context walks slabs s with s % world == rank */
+    int32_t world;
+    uint64_t seed;                 /* Philox key */
+    uint64_t photon_id_base;       /* added to every photon id (independent repeat runs) */
+    double monochromatic_wl;       /* reference global `monochromatic`, MC code.py:88, :387-391; 0 = sample the table */
+    double alpha;                  /* Draine phase-function parameter, Numpy_random_walk.py:16 */
+    double h;                      /* Planck constant used in GetZMomentum (constants.py:10; 1 in the gray script) */
+    const double* tau_atm;         /* [n_atm] reference optical depth of each atmosphere (tau_list_calc) */
+    const uint64_t* n_photons;     /* [n_atm] photons per atmosphere (photon_reduction already applied) */
+} rt_params;
+
+/* Host-side result arrays of one sweep; any pointer may be NULL to skip it. */
+typedef struct rt_tallies {
+    double* sums;          /* [n_atm][RT_NSUM] */
+    uint64_t* counts;      /* [n_atm][RT_NCNT] */
+    uint64_t* mu_hist;     /* [n_atm][n_mu_bins + 1] escape cosines: second-test population for
+                              RT_ORDER_MC (MC code.py:693), the single test for RT_ORDER_GRAY */
+    double* depth_momentum; /* [n_atm][n_depth_bins] dust momentum deposition by depth z / (tau*Scale) */
+    double* depth_energy;   /* [n_atm][n_depth_bins] absorbed w*h by depth */
+    double* slab_sums;     /* [n_atm][n_slabs][RT_NSUM] per-slab partial sums (zero for slabs of other ranks);
+                              summing the slab axis in index order gives `sums` bit for bit on any GPU count */
+} rt_tallies;
+
+/* Per-photon record written by rt_replay. */
+typedef struct rt_photon_trace {
+    double final_z;
+    double final_mu;
+    int32_t fate;      /* RT_FATE_* */
+    int32_t n_scatter; /* scatterings of this photon */
+    int32_t n_draws;   /* uniforms consumed from its stream */
+    int32_t pad_;
+} rt_photon_trace;
+
+typedef struct rt_ctx rt_ctx;
+
+/* Library / device management (no reference counterpart: the reference is single-process NumPy). */
+int rt_abi_version(void);
+const char* rt_last_error(void);
+int rt_create(rt_ctx** out, int device_id);
+int rt_destroy(rt_ctx* ctx);
+/* name[<=256], compute units, wavefront size, clock (kHz) of the context's device */
+int rt_device_info(rt_ctx* ctx, char* name, int name_len, int* n_cu, int* wave_size, int* clock_khz);
+
+/* Optical constants per wavelength and the emission law.
+ * Replaces the table side of CreatePhotons (MC code.py:371-412): wl/g/albedo/scale are the
+ * WL, g, Albedo, Scale columns of Grain_data after the join on WL (MC code.py:403-408);
+ * pdf[i] is the acceptance probability of wavelength i in AcceptReject (MC code.py:239-268),
+ * i.e. P(lambda = wl[i]) is proportional to min(pdf[i], 1).  pdf == NULL means a uniform law.
+ * n_wl == 1 gives gray / monochromatic dust. */
+int rt_set_tables(rt_ctx* ctx, int32_t n_wl, const double* wl, const double* g, const double* albedo,
+                  const double* scale, const double* pdf);
+
+/* The sweep: for every atmosphere a, walk n_photons[a] photons through a slab of optical depth
+ * tau_atm[a] and return the tallies.  Replaces the loop body of runMC (MC code.py:1056-1062)
+ * and RunPhotons (MC code.py:620-779; gray: Numpy_random_walk.py:280-408).
+ * Randomness: Philox4x32-10, key = seed, counter = (photon id lo, hi, block, atmosphere);
+ * results do not depend on rank/world except through which slabs are walked. */
+int rt_run(rt_ctx* ctx, const rt_params* p, rt_tallies* out);
+
+/* Same sweep, results left on the device for a collective:
+ * d_slab_sums  [n_atm][n_slabs][RT_NSUM] doubles, d_counts [n_atm][RT_NCNT] u64,
+ * d_mu_hist [n_atm][n_mu_bins+1] u64, d_depth [2][n_atm][n_depth_bins] doubles (may be NULL when
+ * n_depth_bins == 0).  Buffers are overwritten (zeroed, then filled with this rank's share). The work
+ * is enqueued on `stream` (a hipStream_t passed as void*; NULL = default stream) and NOT synchronised. */
+int rt_run_device(rt_ctx* ctx, const rt_params* p, void* d_slab_sums, void* d_counts, void* d_mu_hist,
+                  void* d_depth, void* stream);
+
+/* Replay: photon i consumes xi[i*max_draws + j], j = 0,1,... instead of Philox, with its constants
+ * given directly (what CreatePhotons would have put in its row).  Used to compare trajectories with
+ * the reference run on identical pre-drawn numbers.  Only n_atm == 1 (tau_atm[0]) is used; a
+ * re-emitted photon (RT_BOUNDARY_REEMIT) restarts with its own constants and mu0.  A photon that
+ * needs more than max_draws uniforms ends with RT_FATE_GUARD. */
+int rt_replay(rt_ctx* ctx, const rt_params* p, int64_t n, int32_t max_draws, const double* xi,
+              const double* lambda, const double* g, const double* albedo, const double* scale,
+              const double* mu0, rt_tallies* out, rt_photon_trace* per_photon);
+
+/* Average kernel time (ms) and launch count of the walk kernel since the last call with reset != 0,
+ * measured with HIP events on the stream the kernel ran on. */
+int rt_kernel_time(rt_ctx* ctx, double* avg_ms, int64_t* launches, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_AMD_H */

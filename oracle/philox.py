@@ -1,0 +1,80 @@
+"""Philox4x32-10 counter-based generator, vectorised with NumPy.
+
+TEST INFRASTRUCTURE ONLY (oracle).  The product's generator is the HIP device
+code in radiative-transfer_amd/csrc; this file restates the published
+Philox4x32-10 algorithm (Salmon et al., SC'11, "Parallel random numbers: as
+easy as 1, 2, 3") so that tests can rebuild the exact uniform streams that
+the device kernels consume.
+
+Stream layout shared by every implementation in this repository:
+
+    key     = (seed_lo, seed_hi)
+    counter = (photon_id_lo, photon_id_hi, block, atmosphere_index)
+    draw j of a photon's walk stream -> block j >> 1, words (2*(j&1), 2*(j&1)+1)
+    uniform = ((w_a >> 5) * 2**26 + (w_b >> 6)) / 2**53      in [0, 1)
+
+The uniform construction is the 53-bit one NumPy's legacy ``random.rand`` uses
+(two 32-bit words -> 27 + 26 bits), so the set of representable draws is the
+same as in the reference scripts, which call ``np.random.rand``
+(MC code.py:496, :479, :436-437).
+"""
+import numpy as np
+
+M0 = np.uint64(0xD2511F53)
+M1 = np.uint64(0xCD9E8D57)
+W0 = 0x9E3779B9
+W1 = 0xBB67AE85
+MASK32 = np.uint64(0xFFFFFFFF)
+EMIT_BLOCK = 0x80000000  # blocks >= this are reserved for emission draws
+
+
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """All arguments broadcastable integer arrays (values < 2**32).
+
+    Returns four uint64 arrays holding the 32-bit output words."""
+    c0, c1, c2, c3 = [np.asarray(x, dtype=np.uint64) & MASK32 for x in (c0, c1, c2, c3)]
+    c0, c1, c2, c3 = np.broadcast_arrays(c0, c1, c2, c3)
+    k0 = int(k0) & 0xFFFFFFFF
+    k1 = int(k1) & 0xFFFFFFFF
+    for _ in range(10):
+        p0 = M0 * c0
+        p1 = M1 * c2
+        hi0, lo0 = p0 >> np.uint64(32), p0 & MASK32
+        hi1, lo1 = p1 >> np.uint64(32), p1 & MASK32
+        c0, c1, c2, c3 = (hi1 ^ c1 ^ np.uint64(k0), lo1, hi0 ^ c3 ^ np.uint64(k1), lo0)
+        k0 = (k0 + W0) & 0xFFFFFFFF
+        k1 = (k1 + W1) & 0xFFFFFFFF
+    return c0, c1, c2, c3
+
+
+def u53(wa, wb):
+    """Two 32-bit words -> double in [0,1) with 53 random bits."""
+    a = np.asarray(wa, dtype=np.uint64) >> np.uint64(5)
+    b = np.asarray(wb, dtype=np.uint64) >> np.uint64(6)
+    return (a.astype(np.float64) * 67108864.0 + b.astype(np.float64)) / 9007199254740992.0
+
+
+def block_uniforms(photon_id, block, atm, seed):
+    """Both uniforms of one Philox block: returns (u_first, u_second)."""
+    pid = np.asarray(photon_id, dtype=np.uint64)
+    w = philox4x32_10(pid & MASK32, pid >> np.uint64(32), block, atm,
+                      seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+    return u53(w[0], w[1]), u53(w[2], w[3])
+
+
+def walk_uniform(photon_id, j, atm, seed):
+    """Draw j (0-based) of the walk stream of each photon."""
+    j = np.asarray(j, dtype=np.uint64)
+    ua, ub = block_uniforms(photon_id, j >> np.uint64(1), atm, seed)
+    return np.where((j & np.uint64(1)) == 0, ua, ub)
+
+
+def walk_matrix(n, max_draws, atm, seed, id_base=0):
+    """xi[n, max_draws] with xi[i, j] = walk_uniform(id_base + i, j)."""
+    ids = (np.arange(n, dtype=np.uint64) + np.uint64(id_base))[:, None]
+    blocks = np.arange((max_draws + 1) // 2, dtype=np.uint64)[None, :]
+    ua, ub = block_uniforms(ids, blocks, atm, seed)
+    out = np.empty((n, 2 * blocks.shape[1]))
+    out[:, 0::2] = ua
+    out[:, 1::2] = ub
+    return np.ascontiguousarray(out[:, :max_draws])

@@ -1,0 +1,92 @@
+"""ctypes mirror of include/rt_amd.h (struct layouts, enums, library loader).
+
+The shared library is built in-tree by ``__graft_entry__.build()`` (hipcc,
+--offload-arch=gfx950) as ``radiative-transfer_amd/csrc/librt_amd.so``.  There
+is no CPU implementation behind this module: if the library is missing or no
+MI355X is visible the calls fail loudly.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "csrc", "librt_amd.so")
+
+RT_ABI_VERSION = 1
+
+BOUNDARY = {"reflect": 0, "absorb": 1, "reemit": 2}
+SCATTER = {"hg": 0, "iso": 1, "draine": 2}
+ORDER = {"mc": 0, "gray": 1}
+
+FATE_ESCAPED, FATE_ESCAPED_UNCOUNTED, FATE_ABSORBED, FATE_BOUNDARY, FATE_GUARD = 1, 2, 3, 4, 5
+
+(SUM_INITIAL, SUM_ESCAPED, SUM_BOUNDARY, SUM_ESCAPED_UNCOUNTED, SUM_TRANSFER_SQ, SUM_TRANSFER_P0,
+ SUM_P0_SQ, SUM_ABSORBED_ENERGY, SUM_DUST_MOMENTUM, SUM_REEMITTED) = range(10)
+NSUM = 10
+(CNT_SCATTER, CNT_ESCAPED, CNT_ESCAPED_UNCOUNTED, CNT_ABSORBED, CNT_BOUNDARY_ABSORBED, CNT_REEMITTED,
+ CNT_GUARD, CNT_PHOTONS, CNT_FLIGHTS, CNT_BOUNDARY_HITS) = range(10)
+NCNT = 10
+
+c_double_p = C.POINTER(C.c_double)
+c_u64_p = C.POINTER(C.c_uint64)
+
+
+class RtParams(C.Structure):
+    _fields_ = [
+        ("n_atm", C.c_int32), ("boundary", C.c_int32), ("scatter", C.c_int32), ("loop_order", C.c_int32),
+        ("rand_mu", C.c_int32), ("abs_only", C.c_int32), ("n_mu_bins", C.c_int32), ("n_depth_bins", C.c_int32),
+        ("max_events_per_photon", C.c_int32), ("n_slabs", C.c_int32), ("rank", C.c_int32), ("world", C.c_int32),
+        ("seed", C.c_uint64), ("photon_id_base", C.c_uint64),
+        ("monochromatic_wl", C.c_double), ("alpha", C.c_double), ("h", C.c_double),
+        ("tau_atm", c_double_p), ("n_photons", c_u64_p),
+    ]
+
+
+class RtTallies(C.Structure):
+    _fields_ = [
+        ("sums", c_double_p), ("counts", c_u64_p), ("mu_hist", c_u64_p),
+        ("depth_momentum", c_double_p), ("depth_energy", c_double_p), ("slab_sums", c_double_p),
+    ]
+
+
+class RtPhotonTrace(C.Structure):
+    _fields_ = [("final_z", C.c_double), ("final_mu", C.c_double), ("fate", C.c_int32),
+                ("n_scatter", C.c_int32), ("n_draws", C.c_int32), ("pad_", C.c_int32)]
+
+
+EXPORTS = ["rt_abi_version", "rt_last_error", "rt_create", "rt_destroy", "rt_device_info", "rt_set_tables",
+           "rt_run", "rt_run_device", "rt_replay", "rt_kernel_time"]
+
+_lib = None
+
+
+def load_library(path=None):
+    """Load librt_amd.so and declare argument types.  Raises OSError if it is not built."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise OSError(f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                      "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    lib = C.CDLL(path)
+    vp = C.c_void_p
+    lib.rt_abi_version.restype = C.c_int
+    lib.rt_last_error.restype = C.c_char_p
+    lib.rt_create.argtypes = [C.POINTER(vp), C.c_int]
+    lib.rt_destroy.argtypes = [vp]
+    lib.rt_device_info.argtypes = [vp, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.rt_set_tables.argtypes = [vp, C.c_int32, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p]
+    lib.rt_run.argtypes = [vp, C.POINTER(RtParams), C.POINTER(RtTallies)]
+    lib.rt_run_device.argtypes = [vp, C.POINTER(RtParams), vp, vp, vp, vp, vp]
+    lib.rt_replay.argtypes = [vp, C.POINTER(RtParams), C.c_int64, C.c_int32, c_double_p, c_double_p, c_double_p,
+                              c_double_p, c_double_p, c_double_p, C.POINTER(RtTallies), C.POINTER(RtPhotonTrace)]
+    lib.rt_kernel_time.argtypes = [vp, c_double_p, C.POINTER(C.c_int64), C.c_int]
+    for name in EXPORTS:
+        getattr(lib, name)  # AttributeError if an entry point is missing
+        if name != "rt_last_error":
+            getattr(lib, name).restype = C.c_int
+    if lib.rt_abi_version() != RT_ABI_VERSION:
+        raise OSError(f"{path}: ABI version {lib.rt_abi_version()} != {RT_ABI_VERSION}")
+    if path == LIB_PATH:
+        _lib = lib
+    return lib

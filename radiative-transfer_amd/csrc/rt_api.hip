@@ -1,0 +1,519 @@
+// rt_api.hip -- C ABI of the library (include/rt_amd.h): context, tables, sweep, replay.
+//
+// Host side only; the kernels are in rt_kernels.hip.  Everything here talks to one GPU through
+// the HIP runtime.  There is no CPU implementation of the walk in this library.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "rt_kernels.hpp"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define RT_HIP(call)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (call);                                                                        \
+        if (e_ != hipSuccess) return fail(RT_ERR_DEVICE, "%s failed: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t n) {
+        if (n <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), n * sizeof(T));
+        if (e == hipSuccess) cap = n;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+struct EventPair {
+    hipEvent_t a, b;
+};
+
+}  // namespace
+
+struct rt_ctx {
+    int device = 0;
+    hipDeviceProp_t prop;
+    hipStream_t stream = nullptr;
+    // tables
+    int32_t n_wl = 0, guide_k = 0;
+    double total = 0.0;
+    std::vector<double> wl;
+    DevBuf<rt::TableRec> d_rec;
+    DevBuf<double> d_cdf;
+    DevBuf<int32_t> d_guide;
+    // sweep workspace
+    DevBuf<rt::AtmPlan> d_plan;
+    DevBuf<uint32_t> d_prefix;
+    DevBuf<double> d_chunk_sums;
+    DevBuf<unsigned int> d_next;
+    // result staging for rt_run / rt_replay
+    DevBuf<double> d_slab_sums, d_depth, d_sums;
+    DevBuf<unsigned long long> d_counts, d_mu_hist;
+    // kernel timing
+    std::vector<EventPair> events;
+    size_t events_used = 0;
+    double ms_total = 0.0;
+    long long launches = 0;
+};
+
+namespace {
+
+int check_common(const rt_params* p) {
+    if (!p) return fail(RT_ERR_INVALID, "params is NULL");
+    if (p->n_atm < 1) return fail(RT_ERR_INVALID, "n_atm must be >= 1 (got %d)", p->n_atm);
+    if (!p->tau_atm || !p->n_photons) return fail(RT_ERR_INVALID, "tau_atm / n_photons is NULL");
+    if (p->boundary < 0 || p->boundary > 2)
+        return fail(RT_ERR_INVALID, "No valid boundary condition specified (boundary=%d)", p->boundary);
+    if (p->scatter < 0 || p->scatter > 2) return fail(RT_ERR_INVALID, "scatter=%d is not hg/iso/draine", p->scatter);
+    if (p->loop_order < 0 || p->loop_order > 1) return fail(RT_ERR_INVALID, "loop_order=%d", p->loop_order);
+    if (p->n_mu_bins < 0 || p->n_mu_bins > 4096) return fail(RT_ERR_LIMIT, "n_mu_bins must be in [0, 4096]");
+    if (p->n_depth_bins < 0 || p->n_depth_bins > 1024) return fail(RT_ERR_LIMIT, "n_depth_bins must be in [0, 1024]");
+    if (p->scatter == RT_SCATTER_DRAINE && p->loop_order != RT_ORDER_GRAY)
+        return fail(RT_ERR_INVALID,
+                    "scatter='draine' is only available with the gray loop order (it is disabled in the "
+                    "wavelength-dependent reference script)");
+    return RT_OK;
+}
+
+rt::Cfg make_cfg(const rt_ctx* ctx, const rt_params* p) {
+    rt::Cfg c;
+    memset(&c, 0, sizeof c);
+    c.boundary = p->boundary;
+    c.scatter = p->scatter;
+    c.order = p->loop_order;
+    c.rand_mu = p->rand_mu != 0;
+    c.abs_only = p->abs_only != 0;
+    c.n_mu_bins = p->n_mu_bins;
+    c.n_depth_bins = p->n_depth_bins;
+    c.max_events = p->max_events_per_photon > 0 ? p->max_events_per_photon : (1 << 20);
+    c.alpha = p->alpha;
+    c.h = p->h;
+    c.k0 = (uint32_t)p->seed;
+    c.k1 = (uint32_t)(p->seed >> 32);
+    c.id_base = p->photon_id_base;
+    c.rec = ctx->d_rec.p;
+    c.cdf = ctx->d_cdf.p;
+    c.guide = ctx->d_guide.p;
+    c.n_wl = ctx->n_wl;
+    c.guide_k = ctx->guide_k;
+    c.mono_index = -1;
+    c.total = ctx->total;
+    return c;
+}
+
+// Chunk length as a function of the atmosphere's photon count only (so that partial sums,
+// and with them every result bit, are the same for any number of GPUs).
+uint32_t chunk_for(unsigned long long n) {
+    if (n >= 8000000ull) return 16384u;
+    if (n >= 2000000ull) return 8192u;
+    if (n >= 250000ull) return 4096u;
+    return 1024u;
+}
+
+void drain_events(rt_ctx* ctx);
+
+hipError_t next_events(rt_ctx* ctx, EventPair** out) {
+    if (ctx->events_used >= 256) drain_events(ctx);  // bound the number of unresolved timings
+    if (ctx->events_used == ctx->events.size()) {
+        EventPair e;
+        hipError_t r = hipEventCreate(&e.a);
+        if (r != hipSuccess) return r;
+        r = hipEventCreate(&e.b);
+        if (r != hipSuccess) return r;
+        ctx->events.push_back(e);
+    }
+    *out = &ctx->events[ctx->events_used++];
+    return hipSuccess;
+}
+
+void drain_events(rt_ctx* ctx) {
+    for (size_t i = 0; i < ctx->events_used; ++i) {
+        float ms = 0.f;
+        if (hipEventSynchronize(ctx->events[i].b) == hipSuccess &&
+            hipEventElapsedTime(&ms, ctx->events[i].a, ctx->events[i].b) == hipSuccess) {
+            ctx->ms_total += ms;
+            ctx->launches += 1;
+        }
+    }
+    ctx->events_used = 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rt_abi_version(void) { return RT_ABI_VERSION; }
+
+const char* rt_last_error(void) { return g_last_error.c_str(); }
+
+int rt_create(rt_ctx** out, int device_id) {
+    if (!out) return fail(RT_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(RT_ERR_DEVICE, "no HIP device visible (%s); this library has no CPU fallback",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    if (device_id < 0 || device_id >= n) return fail(RT_ERR_INVALID, "device_id %d out of range [0,%d)", device_id, n);
+    RT_HIP(hipSetDevice(device_id));
+    rt_ctx* ctx = new rt_ctx();
+    ctx->device = device_id;
+    e = hipGetDeviceProperties(&ctx->prop, device_id);
+    if (e != hipSuccess) {
+        delete ctx;
+        return fail(RT_ERR_DEVICE, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+    }
+    if (strncmp(ctx->prop.gcnArchName, "gfx950", 6) != 0) {
+        std::string arch = ctx->prop.gcnArchName;
+        delete ctx;
+        return fail(RT_ERR_DEVICE, "device %d is %s; this library is built for gfx950 (MI355X) only", device_id,
+                    arch.c_str());
+    }
+    e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete ctx;
+        return fail(RT_ERR_DEVICE, "hipStreamCreate: %s", hipGetErrorString(e));
+    }
+    *out = ctx;
+    return RT_OK;
+}
+
+int rt_destroy(rt_ctx* ctx) {
+    if (!ctx) return RT_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& e : ctx->events) {
+        (void)hipEventDestroy(e.a);
+        (void)hipEventDestroy(e.b);
+    }
+    ctx->d_rec.release();
+    ctx->d_cdf.release();
+    ctx->d_guide.release();
+    ctx->d_plan.release();
+    ctx->d_prefix.release();
+    ctx->d_chunk_sums.release();
+    ctx->d_next.release();
+    ctx->d_slab_sums.release();
+    ctx->d_depth.release();
+    ctx->d_sums.release();
+    ctx->d_counts.release();
+    ctx->d_mu_hist.release();
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return RT_OK;
+}
+
+int rt_device_info(rt_ctx* ctx, char* name, int name_len, int* n_cu, int* wave_size, int* clock_khz) {
+    if (!ctx) return fail(RT_ERR_INVALID, "ctx is NULL");
+    if (name && name_len > 0) snprintf(name, (size_t)name_len, "%s (%s)", ctx->prop.name, ctx->prop.gcnArchName);
+    if (n_cu) *n_cu = ctx->prop.multiProcessorCount;
+    if (wave_size) *wave_size = ctx->prop.warpSize;
+    if (clock_khz) *clock_khz = ctx->prop.clockRate;
+    return RT_OK;
+}
+
+int rt_set_tables(rt_ctx* ctx, int32_t n_wl, const double* wl, const double* g, const double* albedo,
+                  const double* scale, const double* pdf) {
+    if (!ctx) return fail(RT_ERR_INVALID, "ctx is NULL");
+    if (n_wl < 1 || !wl || !g || !albedo || !scale) return fail(RT_ERR_INVALID, "empty or NULL table");
+    if (n_wl > (1 << 24)) return fail(RT_ERR_LIMIT, "n_wl %d exceeds 2^24", n_wl);
+    RT_HIP(hipSetDevice(ctx->device));
+    std::vector<rt::TableRec> rec((size_t)n_wl);
+    std::vector<double> cdf((size_t)n_wl);
+    double acc = 0.0;
+    int last = -1;
+    for (int i = 0; i < n_wl; ++i) {
+        rec[i] = {wl[i], g[i], albedo[i], scale[i]};
+        double p = pdf ? pdf[i] : 1.0;
+        if (!(p > 0.0)) p = 0.0;  // also maps NaN to 0
+        if (p > 1.0) p = 1.0;     // AcceptReject accepts with probability min(PDF, 1)
+        if (p > 0.0) last = i;
+        acc += p;
+        cdf[i] = acc;
+    }
+    if (last < 0) return fail(RT_ERR_INVALID, "emission law has no positive weight");
+    // guide[k] = first index i <= last with cdf[i] > (k/K)*total, or `last` if there is none
+    int K = 64;
+    while (K < n_wl) K <<= 1;
+    std::vector<int32_t> guide((size_t)K + 1);
+    int i = 0;
+    for (int k = 0; k <= K; ++k) {
+        const double t = ((double)k / (double)K) * acc;
+        while (i < last && !(cdf[i] > t)) ++i;
+        guide[k] = i;
+    }
+    guide[K] = last;
+    RT_HIP(ctx->d_rec.reserve((size_t)n_wl));
+    RT_HIP(ctx->d_cdf.reserve((size_t)n_wl));
+    RT_HIP(ctx->d_guide.reserve((size_t)K + 1));
+    RT_HIP(hipStreamSynchronize(ctx->stream));
+    RT_HIP(hipMemcpy(ctx->d_rec.p, rec.data(), sizeof(rt::TableRec) * (size_t)n_wl, hipMemcpyHostToDevice));
+    RT_HIP(hipMemcpy(ctx->d_cdf.p, cdf.data(), sizeof(double) * (size_t)n_wl, hipMemcpyHostToDevice));
+    RT_HIP(hipMemcpy(ctx->d_guide.p, guide.data(), sizeof(int32_t) * ((size_t)K + 1), hipMemcpyHostToDevice));
+    ctx->n_wl = n_wl;
+    ctx->guide_k = K;
+    ctx->total = acc;
+    ctx->wl.assign(wl, wl + n_wl);
+    return RT_OK;
+}
+
+int rt_run_device(rt_ctx* ctx, const rt_params* p, void* d_slab_sums, void* d_counts, void* d_mu_hist, void* d_depth,
+                  void* stream_v) {
+    if (!ctx) return fail(RT_ERR_INVALID, "ctx is NULL");
+    int rc = check_common(p);
+    if (rc) return rc;
+    if (ctx->n_wl < 1) return fail(RT_ERR_STATE, "rt_set_tables must be called before rt_run");
+    if (!d_slab_sums || !d_counts || !d_mu_hist) return fail(RT_ERR_INVALID, "device result buffer is NULL");
+    if (p->n_depth_bins > 0 && !d_depth) return fail(RT_ERR_INVALID, "d_depth is NULL but n_depth_bins > 0");
+    const int n_slabs = p->n_slabs > 0 ? p->n_slabs : 8;
+    const int world = p->world > 0 ? p->world : 1;
+    if (p->rank < 0 || p->rank >= world) return fail(RT_ERR_INVALID, "rank %d not in [0,%d)", p->rank, world);
+    if (n_slabs % world != 0) return fail(RT_ERR_INVALID, "n_slabs (%d) must be a multiple of world (%d)", n_slabs, world);
+    RT_HIP(hipSetDevice(ctx->device));
+    hipStream_t stream = stream_v ? (hipStream_t)stream_v : ctx->stream;
+
+    rt::Cfg cfg = make_cfg(ctx, p);
+    if (p->monochromatic_wl != 0.0) {
+        // CreatePhotons rounds the wavelength to 4 decimals and joins on exact equality (MC code.py:394,403-404).
+        const double want = std::round(p->monochromatic_wl * 1e4) / 1e4;
+        for (int i = 0; i < ctx->n_wl; ++i)
+            if (ctx->wl[i] == want || ctx->wl[i] == p->monochromatic_wl) {
+                cfg.mono_index = i;
+                break;
+            }
+        if (cfg.mono_index < 0)
+            return fail(RT_ERR_INVALID,
+                        "monochromatic wavelength %.6g has no exact match in the table (the reference would loop "
+                        "forever on NaN constants)",
+                        p->monochromatic_wl);
+    }
+
+    // ---- plan: heaviest atmospheres first, chunked per slab ----
+    const uint32_t owned = (uint32_t)(n_slabs / world);
+    std::vector<int> order((size_t)p->n_atm);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+        const double ca = std::min(p->tau_atm[a], 4.0) * (double)p->n_photons[a];
+        const double cb = std::min(p->tau_atm[b], 4.0) * (double)p->n_photons[b];
+        return ca > cb;
+    });
+    std::vector<rt::AtmPlan> plan((size_t)p->n_atm);
+    std::vector<uint32_t> prefix((size_t)p->n_atm + 1);
+    unsigned long long slots = 0, items = 0;
+    for (int k = 0; k < p->n_atm; ++k) {
+        const int a = order[k];
+        rt::AtmPlan& pl = plan[k];
+        pl.tau = p->tau_atm[a];
+        pl.n_photons = p->n_photons[a];
+        pl.slab_len = (pl.n_photons + (unsigned long long)n_slabs - 1) / (unsigned long long)n_slabs;
+        pl.atm = (uint32_t)a;
+        pl.chunk = chunk_for(pl.n_photons);
+        pl.chunks_per_slab = (uint32_t)((pl.slab_len + pl.chunk - 1) / pl.chunk);
+        if (pl.chunks_per_slab == 0) pl.chunks_per_slab = 1;
+        pl.slot_base = (uint32_t)slots;
+        prefix[k] = (uint32_t)items;
+        slots += (unsigned long long)owned * pl.chunks_per_slab;
+        items += (unsigned long long)owned * pl.chunks_per_slab;
+        if (items > 0x7fffffffull) return fail(RT_ERR_LIMIT, "too many work items (%llu)", items);
+    }
+    prefix[p->n_atm] = (uint32_t)items;
+
+    RT_HIP(ctx->d_plan.reserve(plan.size()));
+    RT_HIP(ctx->d_prefix.reserve(prefix.size()));
+    RT_HIP(ctx->d_chunk_sums.reserve((size_t)slots * RT_NSUM));
+    RT_HIP(ctx->d_next.reserve(1));
+    RT_HIP(hipMemcpyAsync(ctx->d_plan.p, plan.data(), sizeof(rt::AtmPlan) * plan.size(), hipMemcpyHostToDevice, stream));
+    RT_HIP(hipMemcpyAsync(ctx->d_prefix.p, prefix.data(), sizeof(uint32_t) * prefix.size(), hipMemcpyHostToDevice,
+                          stream));
+    RT_HIP(hipStreamSynchronize(stream));  // the host vectors go out of scope at return
+
+    rt::Sweep sw;
+    sw.plan = ctx->d_plan.p;
+    sw.item_prefix = ctx->d_prefix.p;
+    sw.n_atm = (uint32_t)p->n_atm;
+    sw.n_items = (uint32_t)items;
+    sw.rank = (uint32_t)p->rank;
+    sw.world = (uint32_t)world;
+    sw.n_slabs = (uint32_t)n_slabs;
+    sw.owned_slabs = owned;
+
+    const size_t nmu = (size_t)p->n_mu_bins + 1;
+    RT_HIP(hipMemsetAsync(ctx->d_next.p, 0, sizeof(unsigned int), stream));
+    RT_HIP(hipMemsetAsync(ctx->d_chunk_sums.p, 0, sizeof(double) * (size_t)slots * RT_NSUM, stream));
+    RT_HIP(hipMemsetAsync(d_slab_sums, 0, sizeof(double) * (size_t)p->n_atm * n_slabs * RT_NSUM, stream));
+    RT_HIP(hipMemsetAsync(d_counts, 0, sizeof(unsigned long long) * (size_t)p->n_atm * RT_NCNT, stream));
+    RT_HIP(hipMemsetAsync(d_mu_hist, 0, sizeof(unsigned long long) * (size_t)p->n_atm * nmu, stream));
+    if (p->n_depth_bins > 0)
+        RT_HIP(hipMemsetAsync(d_depth, 0, sizeof(double) * 2 * (size_t)p->n_atm * p->n_depth_bins, stream));
+
+    const bool fast = p->loop_order == RT_ORDER_MC && p->boundary == RT_BOUNDARY_REFLECT &&
+                      p->scatter == RT_SCATTER_HG && p->n_depth_bins == 0 && !p->abs_only;
+    const size_t lds = rt::walk_lds_bytes(cfg, fast);
+    if (lds > 64 * 1024) return fail(RT_ERR_LIMIT, "histogram bins need %zu bytes of LDS per block (max 65536)", lds);
+    const int per_cu = rt::walk_max_blocks_per_cu(fast, lds);
+    long long grid = (long long)ctx->prop.multiProcessorCount * per_cu;
+    const long long need = ((long long)items + 3) / 4;
+    if (grid > need) grid = need;
+    if (grid < 1) grid = 1;
+
+    EventPair* ev = nullptr;
+    RT_HIP(next_events(ctx, &ev));
+    RT_HIP(hipEventRecord(ev->a, stream));
+    RT_HIP(rt::launch_walk(cfg, sw, fast, (int)grid, stream, ctx->d_next.p, ctx->d_chunk_sums.p,
+                           (unsigned long long*)d_counts, (unsigned long long*)d_mu_hist, (double*)d_depth));
+    RT_HIP(hipEventRecord(ev->b, stream));
+    RT_HIP(rt::launch_slab_reduce(sw, ctx->d_chunk_sums.p, (double*)d_slab_sums, stream));
+    return RT_OK;
+}
+
+int rt_run(rt_ctx* ctx, const rt_params* p, rt_tallies* out) {
+    if (!ctx) return fail(RT_ERR_INVALID, "ctx is NULL");
+    if (!out) return fail(RT_ERR_INVALID, "out is NULL");
+    int rc = check_common(p);
+    if (rc) return rc;
+    const int n_slabs = p->n_slabs > 0 ? p->n_slabs : 8;
+    const size_t na = (size_t)p->n_atm, nmu = (size_t)p->n_mu_bins + 1, nd = (size_t)p->n_depth_bins;
+    RT_HIP(hipSetDevice(ctx->device));
+    RT_HIP(ctx->d_slab_sums.reserve(na * n_slabs * RT_NSUM));
+    RT_HIP(ctx->d_counts.reserve(na * RT_NCNT));
+    RT_HIP(ctx->d_mu_hist.reserve(na * nmu));
+    if (nd) RT_HIP(ctx->d_depth.reserve(2 * na * nd));
+    rc = rt_run_device(ctx, p, ctx->d_slab_sums.p, ctx->d_counts.p, ctx->d_mu_hist.p, nd ? ctx->d_depth.p : nullptr,
+                       ctx->stream);
+    if (rc) return rc;
+    std::vector<double> slab(na * n_slabs * RT_NSUM);
+    RT_HIP(hipMemcpyAsync(slab.data(), ctx->d_slab_sums.p, sizeof(double) * slab.size(), hipMemcpyDeviceToHost,
+                          ctx->stream));
+    if (out->counts)
+        RT_HIP(hipMemcpyAsync(out->counts, ctx->d_counts.p, sizeof(uint64_t) * na * RT_NCNT, hipMemcpyDeviceToHost,
+                              ctx->stream));
+    if (out->mu_hist)
+        RT_HIP(hipMemcpyAsync(out->mu_hist, ctx->d_mu_hist.p, sizeof(uint64_t) * na * nmu, hipMemcpyDeviceToHost,
+                              ctx->stream));
+    if (nd && out->depth_momentum)
+        RT_HIP(hipMemcpyAsync(out->depth_momentum, ctx->d_depth.p, sizeof(double) * na * nd, hipMemcpyDeviceToHost,
+                              ctx->stream));
+    if (nd && out->depth_energy)
+        RT_HIP(hipMemcpyAsync(out->depth_energy, ctx->d_depth.p + na * nd, sizeof(double) * na * nd,
+                              hipMemcpyDeviceToHost, ctx->stream));
+    RT_HIP(hipStreamSynchronize(ctx->stream));
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(RT_ERR_DEVICE, "walk kernel failed: %s", hipGetErrorString(e));
+    if (out->slab_sums) memcpy(out->slab_sums, slab.data(), sizeof(double) * slab.size());
+    if (out->sums) {
+        for (size_t a = 0; a < na; ++a)
+            for (int k = 0; k < RT_NSUM; ++k) {
+                double s = 0.0;
+                for (int sl = 0; sl < n_slabs; ++sl) s += slab[(a * n_slabs + sl) * RT_NSUM + k];
+                out->sums[a * RT_NSUM + k] = s;
+            }
+    }
+    return RT_OK;
+}
+
+int rt_replay(rt_ctx* ctx, const rt_params* p, int64_t n, int32_t max_draws, const double* xi, const double* lambda,
+              const double* g, const double* albedo, const double* scale, const double* mu0, rt_tallies* out,
+              rt_photon_trace* per_photon) {
+    if (!ctx) return fail(RT_ERR_INVALID, "ctx is NULL");
+    int rc = check_common(p);
+    if (rc) return rc;
+    if (n < 0 || max_draws < 0) return fail(RT_ERR_INVALID, "negative size");
+    if (n > 0 && (!xi || !lambda || !g || !albedo || !scale || !mu0)) return fail(RT_ERR_INVALID, "NULL input array");
+    if (!out) return fail(RT_ERR_INVALID, "out is NULL");
+    if ((double)n * (double)max_draws > 4e9) return fail(RT_ERR_LIMIT, "xi matrix larger than 4e9 entries");
+    RT_HIP(hipSetDevice(ctx->device));
+    rt::Cfg cfg = make_cfg(ctx, p);
+    const size_t nn = (size_t)n, nmu = (size_t)p->n_mu_bins + 1, nd = (size_t)p->n_depth_bins;
+    DevBuf<double> d_xi, d_in;
+    DevBuf<rt_photon_trace> d_tr;
+    auto cleanup = [&]() {
+        d_xi.release();
+        d_in.release();
+        d_tr.release();
+    };
+    hipError_t e = hipSuccess;
+    if ((e = d_xi.reserve(std::max<size_t>(nn * (size_t)max_draws, 1))) != hipSuccess ||
+        (e = d_in.reserve(std::max<size_t>(5 * nn, 1))) != hipSuccess ||
+        (e = d_tr.reserve(std::max<size_t>(nn, 1))) != hipSuccess ||
+        (e = ctx->d_sums.reserve(RT_NSUM)) != hipSuccess || (e = ctx->d_counts.reserve(RT_NCNT)) != hipSuccess ||
+        (e = ctx->d_mu_hist.reserve(nmu)) != hipSuccess || (e = ctx->d_depth.reserve(std::max<size_t>(2 * nd, 1))) != hipSuccess) {
+        cleanup();
+        return fail(RT_ERR_DEVICE, "device allocation failed: %s", hipGetErrorString(e));
+    }
+    hipStream_t s = ctx->stream;
+    const double* cols[5] = {lambda, g, albedo, scale, mu0};
+    if (nn) {
+        e = hipMemcpyAsync(d_xi.p, xi, sizeof(double) * nn * (size_t)max_draws, hipMemcpyHostToDevice, s);
+        for (int c = 0; c < 5 && e == hipSuccess; ++c)
+            e = hipMemcpyAsync(d_in.p + c * nn, cols[c], sizeof(double) * nn, hipMemcpyHostToDevice, s);
+    }
+    if (e == hipSuccess) e = hipMemsetAsync(ctx->d_sums.p, 0, sizeof(double) * RT_NSUM, s);
+    if (e == hipSuccess) e = hipMemsetAsync(ctx->d_counts.p, 0, sizeof(uint64_t) * RT_NCNT, s);
+    if (e == hipSuccess) e = hipMemsetAsync(ctx->d_mu_hist.p, 0, sizeof(uint64_t) * nmu, s);
+    if (e == hipSuccess && nd) e = hipMemsetAsync(ctx->d_depth.p, 0, sizeof(double) * 2 * nd, s);
+    if (e == hipSuccess)
+        e = rt::launch_replay(cfg, p->tau_atm[0], (long long)n, max_draws, d_xi.p, d_in.p, d_in.p + nn, d_in.p + 2 * nn,
+                              d_in.p + 3 * nn, d_in.p + 4 * nn, ctx->d_sums.p, ctx->d_counts.p, ctx->d_mu_hist.p,
+                              ctx->d_depth.p, d_tr.p, s);
+    if (e == hipSuccess && out->sums) e = hipMemcpyAsync(out->sums, ctx->d_sums.p, sizeof(double) * RT_NSUM, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess && out->counts)
+        e = hipMemcpyAsync(out->counts, ctx->d_counts.p, sizeof(uint64_t) * RT_NCNT, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess && out->mu_hist)
+        e = hipMemcpyAsync(out->mu_hist, ctx->d_mu_hist.p, sizeof(uint64_t) * nmu, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess && nd && out->depth_momentum)
+        e = hipMemcpyAsync(out->depth_momentum, ctx->d_depth.p, sizeof(double) * nd, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess && nd && out->depth_energy)
+        e = hipMemcpyAsync(out->depth_energy, ctx->d_depth.p + nd, sizeof(double) * nd, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess && per_photon && nn)
+        e = hipMemcpyAsync(per_photon, d_tr.p, sizeof(rt_photon_trace) * nn, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    cleanup();
+    if (e != hipSuccess) return fail(RT_ERR_DEVICE, "replay failed: %s", hipGetErrorString(e));
+    return RT_OK;
+}
+
+int rt_kernel_time(rt_ctx* ctx, double* avg_ms, int64_t* launches, int reset) {
+    if (!ctx) return fail(RT_ERR_INVALID, "ctx is NULL");
+    (void)hipSetDevice(ctx->device);
+    drain_events(ctx);
+    if (avg_ms) *avg_ms = ctx->launches ? ctx->ms_total / (double)ctx->launches : 0.0;
+    if (launches) *launches = ctx->launches;
+    if (reset) {
+        ctx->ms_total = 0.0;
+        ctx->launches = 0;
+    }
+    return RT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,363 @@
+// rt_device.hpp -- device-side building blocks of the photon random walk (gfx950).
+//
+// One photon lives in the registers of one lane.  The functions here are the
+// per-lane pieces: the counter-based generator, the emission lookup and one
+// loop iteration ("flight": step, boundary/escape tests, absorption,
+// scattering).  The kernels in rt_kernels.hip wrap them in a persistent
+// wave-level loop (production) or a one-photon-per-thread loop (replay).
+//
+// Reference semantics implemented (file:line into the reference checkout):
+//   TakeStep            MC code.py:493-508
+//   CheckForEscape      MC code.py:576-593   (strict >, tested twice in RT_ORDER_MC)
+//   CheckBoundary       MC code.py:522-574   (<=)
+//   Absorb              MC code.py:470-491   (xi > Albedo)
+//   HGScatter           MC code.py:427-441
+//   IsoScatter          MC code.py:414-425
+//   RotateIntoLabFrame  MC code.py:595-618
+//   GetZMomentum        MC code.py:360-369
+//   gray-dust loop      Numpy_random_walk.py:313-396
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/rt_amd.h"
+
+namespace rt {
+
+constexpr uint32_t kEmitBlock = 0x80000000u;  // Philox blocks >= this feed photon emission
+constexpr double kTwoPi = 2 * 3.141592653589793;
+
+// ---------------------------------------------------------------------------
+// Philox4x32-10.  counter = (photon id lo, hi, block, atmosphere), key = seed.
+// ---------------------------------------------------------------------------
+struct PhiloxOut {
+    uint32_t w0, w1, w2, w3;
+};
+
+__device__ __forceinline__ PhiloxOut philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                                   uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (uint32_t)p1;
+        c3 = (uint32_t)p0;
+        c0 = n0;
+        c2 = n2;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return {c0, c1, c2, c3};
+}
+
+// 53-bit uniform in [0,1): the construction NumPy's legacy random.rand uses.
+__device__ __forceinline__ double u53(uint32_t a, uint32_t b) {
+    return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) * (1.0 / 9007199254740992.0);
+}
+
+// ---------------------------------------------------------------------------
+// Run configuration (wave-uniform; passed by value as a kernel argument).
+// ---------------------------------------------------------------------------
+struct TableRec {  // one wavelength: what CreatePhotons copies into a photon row
+    double lam, g, albedo, scale;
+};
+
+struct Cfg {
+    int32_t boundary, scatter, order, rand_mu, abs_only;
+    int32_t n_mu_bins, n_depth_bins, max_events;
+    double alpha, h;
+    uint32_t k0, k1;
+    uint64_t id_base;
+    // emission tables
+    const TableRec* rec;
+    const double* cdf;     // unnormalised cumulative weights, n_wl entries
+    const int32_t* guide;  // guide[k] = first index whose cdf exceeds (k/K)*total, K+1 entries
+    int32_t n_wl, guide_k, mono_index;
+    double total;
+};
+
+struct Photon {
+    double z, mu, wh, g, albedo, zmax, inv2g, opg2, omg2, p0, e1, b;
+    uint32_t iter;
+    int32_t n_scatter;
+};
+
+struct Acc {
+    double s[RT_NSUM];
+    uint32_t c[RT_NCNT];
+    __device__ __forceinline__ void clear() {
+#pragma unroll
+        for (int k = 0; k < RT_NSUM; ++k) s[k] = 0.0;
+#pragma unroll
+        for (int k = 0; k < RT_NCNT; ++k) c[k] = 0u;
+    }
+};
+
+// Wave-private histograms in LDS (pointers are null when the tally is off).
+struct Hist {
+    uint32_t* mu;
+    double* depth_mom;
+    double* depth_en;
+};
+
+// ---------------------------------------------------------------------------
+// Random sources.  Draws are consumed in aligned pairs:
+//   pair 2k   -> (step, absorb)      pair 2k+1 -> (azimuth, cosine)
+// which is the per-photon order of the reference loop (MC code.py:496,479,436-437).
+// ---------------------------------------------------------------------------
+struct PhiloxSrc {
+    uint32_t id_lo, id_hi, atm, k0, k1;
+    uint32_t blk;     // next walk block
+    uint32_t n_emit;  // emissions so far
+    static constexpr bool kBounded = false;
+    __device__ __forceinline__ int pair(double& a, double& b) {
+        const PhiloxOut o = philox4x32_10(id_lo, id_hi, blk, atm, k0, k1);
+        ++blk;
+        a = u53(o.w0, o.w1);
+        b = u53(o.w2, o.w3);
+        return 2;
+    }
+    __device__ __forceinline__ void emit_pair(double& a, double& b) {
+        const PhiloxOut o = philox4x32_10(id_lo, id_hi, kEmitBlock + n_emit, atm, k0, k1);
+        ++n_emit;
+        a = u53(o.w0, o.w1);
+        b = u53(o.w2, o.w3);
+    }
+    __device__ __forceinline__ void used(int) {}
+};
+
+struct ReplaySrc {
+    const double* xi;  // this photon's row
+    int32_t max_draws;
+    int32_t j;       // next pair starts here
+    int32_t n_used;  // uniforms logically consumed
+    static constexpr bool kBounded = true;
+    __device__ __forceinline__ int pair(double& a, double& b) {
+        const int avail = max_draws - j;
+        a = avail > 0 ? xi[j] : 0.5;
+        b = avail > 1 ? xi[j + 1] : 0.5;
+        j += 2;
+        return avail > 2 ? 2 : (avail < 0 ? 0 : avail);
+    }
+    __device__ __forceinline__ void used(int n) { n_used += n; }
+};
+
+// ---------------------------------------------------------------------------
+// Emission: wavelength index from the tabulated law, then the photon constants.
+// P(index i) is proportional to min(max(pdf_i,0),1)  (AcceptReject, MC code.py:239-268).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int sample_index(const Cfg& cfg, double u) {
+    if (cfg.mono_index >= 0) return cfg.mono_index;
+    const double t = u * cfg.total;
+    const int k = (int)(u * (double)cfg.guide_k);
+    int lo = cfg.guide[k];
+    int hi = cfg.guide[k + 1];
+    while (lo < hi) {  // first i in [lo, hi] with cdf[i] > t (hi is the fallback)
+        const int mid = lo + ((hi - lo) >> 1);
+        if (cfg.cdf[mid] > t)
+            hi = mid;
+        else
+            lo = mid + 1;
+    }
+    return lo;
+}
+
+__device__ __forceinline__ void set_constants(const Cfg& cfg, double tau, double lam, double g, double albedo,
+                                              double scale, double mu0, Photon& ph) {
+    const double w = cfg.order == RT_ORDER_GRAY ? lam : 1.0 / lam;
+    ph.wh = w * cfg.h;
+    ph.g = g;
+    ph.albedo = albedo;
+    ph.zmax = tau * scale;
+    ph.inv2g = 1.0 / (2.0 * g);
+    ph.opg2 = 1.0 + g * g;
+    ph.omg2 = 1.0 - g * g;
+    ph.z = 0.0;
+    ph.mu = mu0;
+}
+
+__device__ __forceinline__ void emit_from_table(const Cfg& cfg, double tau, PhiloxSrc& src, Photon& ph) {
+    double ua, ub;
+    src.emit_pair(ua, ub);
+    const int i = sample_index(cfg, ua);
+    const TableRec r = cfg.rec[i];
+    set_constants(cfg, tau, r.lam, r.g, r.albedo, r.scale, cfg.rand_mu ? ub : 1.0, ph);
+}
+
+__device__ __forceinline__ int depth_bin(const Cfg& cfg, const Photon& ph) {
+    int k = (int)floor((double)cfg.n_depth_bins * (ph.z / ph.zmax));
+    k = k < 0 ? 0 : k;
+    return k >= cfg.n_depth_bins ? cfg.n_depth_bins - 1 : k;
+}
+
+__device__ __forceinline__ double draine_pdf(double g, double alpha, double m) {
+    // Numpy_random_walk.py:124
+    return 1.0 / (4.0 * 3.141592653589793) * (1.0 - g * g) / (1.0 + alpha * (1.0 + 2.0 * g * g) / 3.0) *
+           (1.0 + alpha * m * m) / pow(1.0 + g * g - 2.0 * g * m, 1.5);
+}
+
+// ---------------------------------------------------------------------------
+// One loop iteration of one photon.  Returns 0 while the photon is alive,
+// otherwise its RT_FATE_*.  FAST fixes (RT_ORDER_MC, reflect, hg, no depth
+// bins, abs_only off) at compile time; the generic form reads cfg.
+// `reemit` is called when a photon is re-emitted at the lower boundary.
+// ---------------------------------------------------------------------------
+template <bool FAST, class Src, class Reemit>
+__device__ __forceinline__ int flight(const Cfg& cfg, Photon& ph, Src& src, Acc& acc, const Hist& hist,
+                                      Reemit&& reemit) {
+    const bool gray = FAST ? false : cfg.order == RT_ORDER_GRAY;
+    const int boundary = FAST ? (int)RT_BOUNDARY_REFLECT : cfg.boundary;
+    const int scatter = FAST ? (int)RT_SCATTER_HG : cfg.scatter;
+    const bool depth = FAST ? false : cfg.n_depth_bins > 0;
+
+    double u_step, u_abs;
+    if (ph.iter >= (uint32_t)cfg.max_events) return RT_FATE_GUARD;
+    const int avail = src.pair(u_step, u_abs);
+    if (Src::kBounded && avail < 1) return RT_FATE_GUARD;
+    ph.iter++;
+    acc.c[RT_CNT_FLIGHTS]++;
+    src.used(1);
+
+    // TakeStep
+    ph.z += -log(u_step) * ph.mu;
+
+    if (!gray && ph.z > ph.zmax) {  // first escape test: momentum tallied
+        ph.e1 = ph.mu * ph.wh;
+        return RT_FATE_ESCAPED;
+    }
+    if (ph.z <= 0.0) {  // CheckBoundary
+        const double pb = ph.mu * ph.wh;
+        acc.c[RT_CNT_BOUNDARY_HITS]++;
+        if (boundary == RT_BOUNDARY_REFLECT) {
+            ph.b -= pb;
+            ph.z = -ph.z;
+            ph.mu = -ph.mu;
+        } else if (boundary == RT_BOUNDARY_ABSORB) {
+            ph.b += pb;
+            return RT_FATE_BOUNDARY;
+        } else {
+            ph.b += pb;
+            acc.c[RT_CNT_REEMITTED]++;
+            reemit(ph);
+            acc.s[RT_SUM_REEMITTED] += ph.mu * ph.wh;
+        }
+    }
+    if (ph.z > ph.zmax) {  // second escape test (the only one in gray order)
+        if (gray) {
+            ph.e1 = ph.mu * ph.wh;
+            return RT_FATE_ESCAPED;
+        }
+        acc.s[RT_SUM_ESCAPED_UNCOUNTED] += ph.mu * ph.wh;
+        return RT_FATE_ESCAPED_UNCOUNTED;
+    }
+
+    // Absorb
+    if (Src::kBounded && avail < 2) return RT_FATE_GUARD;
+    src.used(1);
+    const bool absorbed = (!FAST && cfg.abs_only) ? (u_abs > 0.0) : (u_abs > ph.albedo);
+    if (absorbed) {
+        const double pa = ph.mu * ph.wh;
+        acc.s[RT_SUM_DUST_MOMENTUM] += pa;
+        acc.s[RT_SUM_ABSORBED_ENERGY] += ph.wh;
+        if (depth) {
+            const int k = depth_bin(cfg, ph);
+            atomicAdd(&hist.depth_mom[k], pa);
+            atomicAdd(&hist.depth_en[k], ph.wh);
+        }
+        return RT_FATE_ABSORBED;
+    }
+
+    // Scatter
+    double u_phi, u_s;
+    const int avail2 = src.pair(u_phi, u_s);
+    if (Src::kBounded && avail2 < 2) return RT_FATE_GUARD;
+    src.used(2);
+    const double mu_old = ph.mu;
+    bool iso = false;
+    if (!FAST) {
+        if (scatter == RT_SCATTER_ISO) iso = gray ? true : (ph.iter == 1u);
+        if (gray && scatter == RT_SCATTER_HG && ph.g == 0.0) iso = true;
+    }
+    double mu_prime;
+    bool direct = false;
+    if (!FAST && scatter == RT_SCATTER_DRAINE && !iso) {
+        mu_prime = 0.0;
+        bool ok = false;
+        for (;;) {  // rejection sampling of the Draine phase function, one pair (y, candidate) per try
+            double y, cand;
+            const int av = src.pair(y, cand);
+            if (Src::kBounded && av < 2) break;
+            src.used(2);
+            cand = 2.0 * cand - 1.0;
+            if (draine_pdf(ph.g, cfg.alpha, cand) > y) {
+                mu_prime = cand;
+                ok = true;
+                break;
+            }
+        }
+        if (!ok) return RT_FATE_GUARD;
+    } else {
+        const double s = 2.0 * u_s - 1.0;
+        if (iso) {
+            mu_prime = s;
+            direct = true;
+        } else {
+            const double q = ph.omg2 / (1.0 + ph.g * s);
+            mu_prime = ph.inv2g * (ph.opg2 - q * q);
+        }
+    }
+    // RotateIntoLabFrame
+    double mu_new;
+    if (direct || mu_old == 1.0) {
+        mu_new = mu_prime;
+    } else if (mu_old == -1.0) {
+        mu_new = -mu_prime;
+    } else {
+        const double phi = kTwoPi * u_phi;
+        mu_new = -sqrt(1.0 - mu_old * mu_old) * sqrt(1.0 - mu_prime * mu_prime) * cos(phi) + mu_old * mu_prime;
+    }
+    ph.mu = mu_new;
+    ph.n_scatter++;
+    acc.c[RT_CNT_SCATTER]++;
+    const double dp = (mu_old - mu_new) * ph.wh;
+    acc.s[RT_SUM_DUST_MOMENTUM] += dp;
+    if (depth) atomicAdd(&hist.depth_mom[depth_bin(cfg, ph)], dp);
+    return 0;
+}
+
+// Bookkeeping when a photon's history ends.
+__device__ __forceinline__ void retire(const Cfg& cfg, const Photon& ph, int fate, Acc& acc, const Hist& hist) {
+    const bool gray = cfg.order == RT_ORDER_GRAY;
+    acc.c[RT_CNT_ESCAPED] += fate == RT_FATE_ESCAPED;
+    acc.c[RT_CNT_ESCAPED_UNCOUNTED] += fate == RT_FATE_ESCAPED_UNCOUNTED;
+    acc.c[RT_CNT_ABSORBED] += fate == RT_FATE_ABSORBED;
+    acc.c[RT_CNT_BOUNDARY_ABSORBED] += fate == RT_FATE_BOUNDARY;
+    acc.c[RT_CNT_GUARD] += fate == RT_FATE_GUARD;
+    acc.s[RT_SUM_ESCAPED] += ph.e1;
+    acc.s[RT_SUM_BOUNDARY] += ph.b;
+    const double t = ph.p0 - ph.e1 + ph.b;
+    acc.s[RT_SUM_TRANSFER_SQ] += t * t;
+    acc.s[RT_SUM_TRANSFER_P0] += t * ph.p0;
+    acc.s[RT_SUM_P0_SQ] += ph.p0 * ph.p0;
+    if (hist.mu && ((fate == RT_FATE_ESCAPED && gray) || fate == RT_FATE_ESCAPED_UNCOUNTED)) {
+        int k = (int)floor((double)cfg.n_mu_bins * ph.mu);
+        k = k < 0 ? 0 : k;
+        k = k > cfg.n_mu_bins ? cfg.n_mu_bins : k;
+        atomicAdd(&hist.mu[k], 1u);
+    }
+}
+
+__device__ __forceinline__ void start_photon(Photon& ph, Acc& acc) {
+    ph.p0 = ph.mu * ph.wh;
+    ph.e1 = 0.0;
+    ph.b = 0.0;
+    ph.iter = 0u;
+    ph.n_scatter = 0;
+    acc.s[RT_SUM_INITIAL] += ph.p0;
+    acc.c[RT_CNT_PHOTONS]++;
+}
+
+}  // namespace rt

@@ -1,0 +1,310 @@
+// rt_kernels.hip -- gfx950 kernels of the photon random walk and their launchers.
+//
+//   walk_kernel<FAST>   persistent scatter kernel.  Every wave pulls work items
+//                       (atmosphere, chunk of photon ids) from a global queue; inside a
+//                       chunk each lane carries one photon in registers and dead lanes are
+//                       refilled from the chunk with a ballot / prefix count.  A chunk is
+//                       walked by exactly one wave and its lanes are reduced in a fixed
+//                       butterfly, so a chunk's partial sums depend only on the photon
+//                       ids in it, not on which wave, CU or GPU ran it.
+//   slab_reduce_kernel  sums the chunk partials of a slab in chunk order.
+//   replay_kernel       one photon per thread on caller-supplied uniforms.
+//
+// Replaces RunPhotons (MC code.py:620-779, Numpy_random_walk.py:280-408) and the
+// atmosphere loop of runMC (MC code.py:1056-1062).
+#include "rt_kernels.hpp"
+
+namespace rt {
+
+constexpr int kWavesPerBlock = kWalkBlock / 64;
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// LDS layout per block: [waves][2*nd] doubles (depth momentum, depth energy), then [waves][nmu] u32.
+__device__ __forceinline__ Hist wave_hist(unsigned char* lds_raw, int wave, int nmu, int nd) {
+    double* depth_base = reinterpret_cast<double*>(lds_raw) + (size_t)wave * 2 * nd;
+    uint32_t* mu_base =
+        reinterpret_cast<uint32_t*>(lds_raw + sizeof(double) * (size_t)kWavesPerBlock * 2 * nd) + (size_t)wave * nmu;
+    Hist h;
+    h.mu = mu_base;
+    h.depth_mom = nd ? depth_base : nullptr;
+    h.depth_en = nd ? depth_base + nd : nullptr;
+    return h;
+}
+
+__device__ __forceinline__ void clear_hist(const Hist& h, int lane, int nmu, int nd) {
+    for (int k = lane; k < nmu; k += 64) h.mu[k] = 0u;
+    for (int k = lane; k < 2 * nd; k += 64) h.depth_mom[k] = 0.0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// Moves the wave's LDS histograms into the global tallies of atmosphere `atm` and zeroes them.
+__device__ __forceinline__ void flush_hist(const Hist& h, int lane, int nmu, int nd, uint32_t atm, uint32_t n_atm,
+                                           unsigned long long* d_mu_hist, double* d_depth) {
+    __builtin_amdgcn_wave_barrier();
+    for (int k = lane; k < nmu; k += 64) {
+        const uint32_t v = atomicExch(&h.mu[k], 0u);
+        if (v) atomicAdd(&d_mu_hist[(size_t)atm * nmu + k], (unsigned long long)v);
+    }
+    for (int k = lane; k < 2 * nd; k += 64) {
+        const unsigned long long bits = atomicExch(reinterpret_cast<unsigned long long*>(&h.depth_mom[k]), 0ull);
+        const double v = __longlong_as_double((long long)bits);
+        const int which = k >= nd;  // 0: momentum, 1: energy
+        if (v != 0.0) atomicAdd(&d_depth[((size_t)which * n_atm + atm) * nd + (k - which * nd)], v);
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <bool FAST>
+__global__ __launch_bounds__(kWalkBlock) void walk_kernel(const Cfg cfg, const Sweep sw,
+                                                           unsigned int* __restrict__ d_next,
+                                                           double* __restrict__ d_chunk_sums,
+                                                           unsigned long long* __restrict__ d_counts,
+                                                           unsigned long long* __restrict__ d_mu_hist,
+                                                           double* __restrict__ d_depth) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int nmu = cfg.n_mu_bins + 1;
+    const int nd = FAST ? 0 : cfg.n_depth_bins;
+    const Hist hist = wave_hist(lds_raw, wave, nmu, nd);
+    clear_hist(hist, lane, nmu, nd);
+
+    for (;;) {
+        // ---- pop one work item (wave-uniform) ----
+        unsigned int q = 0;
+        if (lane == 0) q = atomicAdd(d_next, 1u);
+        q = __builtin_amdgcn_readfirstlane(q);
+        if (q >= sw.n_items) break;
+        int lo = 0, hi = (int)sw.n_atm;  // sorted position with item_prefix[lo] <= q < item_prefix[lo+1]
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (sw.item_prefix[mid] <= q)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        const AtmPlan plan = sw.plan[lo];
+        const unsigned int local = q - sw.item_prefix[lo];
+        const unsigned int j = local / plan.chunks_per_slab;  // ordinal among the slabs this rank owns
+        const unsigned int c = local - j * plan.chunks_per_slab;
+        const unsigned long long slab = (unsigned long long)sw.rank + (unsigned long long)j * sw.world;
+        const unsigned long long slab_lo = slab * plan.slab_len;
+        unsigned long long slab_hi = slab_lo + plan.slab_len;
+        slab_hi = slab_hi < plan.n_photons ? slab_hi : plan.n_photons;
+        unsigned long long cursor = slab_lo + (unsigned long long)c * plan.chunk;
+        unsigned long long end = cursor + plan.chunk;
+        end = end < slab_hi ? end : slab_hi;
+        const double tau = plan.tau;
+        const uint32_t atm = plan.atm;
+
+        Acc acc;
+        acc.clear();
+        Photon ph = {};
+        PhiloxSrc src = {};
+        src.atm = atm;
+        src.k0 = cfg.k0;
+        src.k1 = cfg.k1;
+        bool alive = false;
+
+        auto reemit = [&](Photon& p) {
+            const double p0 = p.p0, e1 = p.e1, b = p.b;
+            const uint32_t it = p.iter;
+            const int ns = p.n_scatter;
+            emit_from_table(cfg, tau, src, p);
+            p.p0 = p0;
+            p.e1 = e1;
+            p.b = b;
+            p.iter = it;
+            p.n_scatter = ns;
+        };
+
+        for (;;) {
+            // ---- refill dead lanes from the chunk (ballot + prefix count) ----
+            const unsigned long long dead = __ballot(!alive);
+            if (dead != 0ull && cursor < end) {
+                const unsigned int my_off =
+                    __builtin_amdgcn_mbcnt_hi((uint32_t)(dead >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dead, 0u));
+                const unsigned long long my_id = cursor + my_off;
+                if (!alive && my_id < end) {
+                    const unsigned long long gid = my_id + cfg.id_base;
+                    src.id_lo = (uint32_t)gid;
+                    src.id_hi = (uint32_t)(gid >> 32);
+                    src.blk = 0u;
+                    src.n_emit = 0u;
+                    emit_from_table(cfg, tau, src, ph);
+                    start_photon(ph, acc);
+                    alive = true;
+                }
+                cursor += (unsigned long long)__popcll(dead);
+            }
+            if (__ballot(alive) == 0ull) break;
+            // ---- one flight for every live lane ----
+            if (alive) {
+                const int fate = flight<FAST>(cfg, ph, src, acc, hist, reemit);
+                if (fate != 0) {
+                    retire(cfg, ph, fate, acc, hist);
+                    alive = false;
+                }
+            }
+        }
+
+        // ---- chunk epilogue: fixed-order lane reduction, one partial per chunk ----
+        const size_t slot = (size_t)plan.slot_base + (size_t)j * plan.chunks_per_slab + c;
+#pragma unroll
+        for (int k = 0; k < RT_NSUM; ++k) {
+            const double v = wave_sum(acc.s[k]);
+            if (lane == 0) d_chunk_sums[slot * RT_NSUM + k] = v;
+        }
+#pragma unroll
+        for (int k = 0; k < RT_NCNT; ++k) {
+            const uint32_t v = wave_sum_u32(acc.c[k]);
+            if (lane == 0 && v) atomicAdd(&d_counts[(size_t)atm * RT_NCNT + k], (unsigned long long)v);
+        }
+        flush_hist(hist, lane, nmu, nd, atm, sw.n_atm, d_mu_hist, d_depth);
+    }
+}
+
+// One thread per (sorted atmosphere, owned slab, tally): chunk partials summed in chunk order.
+__global__ void slab_reduce_kernel(const Sweep sw, const double* __restrict__ d_chunk_sums,
+                                   double* __restrict__ d_slab_sums) {
+    const unsigned int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned int per_atm = sw.owned_slabs * RT_NSUM;
+    if (t >= sw.n_atm * per_atm) return;
+    const unsigned int a = t / per_atm;
+    const unsigned int r = t - a * per_atm;
+    const unsigned int j = r / RT_NSUM;
+    const unsigned int k = r - j * RT_NSUM;
+    const AtmPlan plan = sw.plan[a];
+    const unsigned int slab = sw.rank + j * sw.world;
+    if (slab >= sw.n_slabs) return;
+    const double* src = d_chunk_sums + ((size_t)plan.slot_base + (size_t)j * plan.chunks_per_slab) * RT_NSUM + k;
+    double s = 0.0;
+    // chunks beyond the end of the atmosphere were never queued: count the real ones
+    const unsigned long long slab_lo = (unsigned long long)slab * plan.slab_len;
+    unsigned long long slab_hi = slab_lo + plan.slab_len;
+    slab_hi = slab_hi < plan.n_photons ? slab_hi : plan.n_photons;
+    const unsigned long long len = slab_hi > slab_lo ? slab_hi - slab_lo : 0ull;
+    const unsigned int n_chunks = (unsigned int)((len + plan.chunk - 1) / plan.chunk);
+    for (unsigned int c = 0; c < n_chunks; ++c) s += src[(size_t)c * RT_NSUM];
+    d_slab_sums[((size_t)plan.atm * sw.n_slabs + slab) * RT_NSUM + k] = s;
+}
+
+__global__ __launch_bounds__(kWalkBlock) void replay_kernel(const Cfg cfg, const double tau, const long long n,
+                                                            const int max_draws, const double* __restrict__ xi,
+                                                            const double* __restrict__ lam,
+                                                            const double* __restrict__ g,
+                                                            const double* __restrict__ albedo,
+                                                            const double* __restrict__ scale,
+                                                            const double* __restrict__ mu0, double* d_sums,
+                                                            unsigned long long* d_counts,
+                                                            unsigned long long* d_mu_hist, double* d_depth,
+                                                            rt_photon_trace* __restrict__ trace) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int nmu = cfg.n_mu_bins + 1;
+    const int nd = cfg.n_depth_bins;
+    const Hist hist = wave_hist(lds_raw, wave, nmu, nd);
+    clear_hist(hist, lane, nmu, nd);
+
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    Acc acc;
+    acc.clear();
+    if (i < n) {
+        Photon ph = {};
+        ReplaySrc src;
+        src.xi = xi + (size_t)i * (size_t)max_draws;
+        src.max_draws = max_draws;
+        src.j = 0;
+        src.n_used = 0;
+        set_constants(cfg, tau, lam[i], g[i], albedo[i], scale[i], mu0[i], ph);
+        start_photon(ph, acc);
+        auto reemit = [&](Photon& p) {
+            p.z = 0.0;
+            p.mu = mu0[i];
+        };
+        int fate = 0;
+        while (fate == 0) fate = flight<false>(cfg, ph, src, acc, hist, reemit);
+        retire(cfg, ph, fate, acc, hist);
+        if (trace) {
+            rt_photon_trace t;
+            t.final_z = ph.z;
+            t.final_mu = ph.mu;
+            t.fate = fate;
+            t.n_scatter = ph.n_scatter;
+            t.n_draws = src.n_used;
+            t.pad_ = 0;
+            trace[i] = t;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < RT_NSUM; ++k) {
+        const double v = wave_sum(acc.s[k]);
+        if (lane == 0 && v != 0.0) atomicAdd(&d_sums[k], v);
+    }
+#pragma unroll
+    for (int k = 0; k < RT_NCNT; ++k) {
+        const uint32_t v = wave_sum_u32(acc.c[k]);
+        if (lane == 0 && v) atomicAdd(&d_counts[k], (unsigned long long)v);
+    }
+    flush_hist(hist, lane, nmu, nd, 0u, 1u, d_mu_hist, d_depth);
+}
+
+// ------------------------------- launchers -------------------------------
+size_t walk_lds_bytes(const Cfg& cfg, bool fast) {
+    const size_t nd = fast ? 0 : (size_t)cfg.n_depth_bins;
+    return sizeof(double) * kWavesPerBlock * 2 * nd + sizeof(uint32_t) * kWavesPerBlock * ((size_t)cfg.n_mu_bins + 1);
+}
+
+int walk_max_blocks_per_cu(bool fast, size_t lds_bytes) {
+    int nb = 0;
+    hipError_t e = fast ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, walk_kernel<true>, kWalkBlock, lds_bytes)
+                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, walk_kernel<false>, kWalkBlock, lds_bytes);
+    if (e != hipSuccess || nb < 1) nb = 1;
+    return nb;
+}
+
+hipError_t launch_walk(const Cfg& cfg, const Sweep& sw, bool fast, int grid, hipStream_t stream,
+                       unsigned int* d_next, double* d_chunk_sums, unsigned long long* d_counts,
+                       unsigned long long* d_mu_hist, double* d_depth) {
+    const size_t lds = walk_lds_bytes(cfg, fast);
+    if (fast)
+        walk_kernel<true><<<grid, kWalkBlock, lds, stream>>>(cfg, sw, d_next, d_chunk_sums, d_counts, d_mu_hist, d_depth);
+    else
+        walk_kernel<false><<<grid, kWalkBlock, lds, stream>>>(cfg, sw, d_next, d_chunk_sums, d_counts, d_mu_hist, d_depth);
+    return hipGetLastError();
+}
+
+hipError_t launch_slab_reduce(const Sweep& sw, const double* d_chunk_sums, double* d_slab_sums, hipStream_t stream) {
+    const unsigned int total = sw.n_atm * sw.owned_slabs * RT_NSUM;
+    if (total == 0) return hipSuccess;
+    slab_reduce_kernel<<<(total + 255) / 256, 256, 0, stream>>>(sw, d_chunk_sums, d_slab_sums);
+    return hipGetLastError();
+}
+
+hipError_t launch_replay(const Cfg& cfg, double tau, long long n, int max_draws, const double* d_xi,
+                         const double* d_lam, const double* d_g, const double* d_albedo, const double* d_scale,
+                         const double* d_mu0, double* d_sums, unsigned long long* d_counts,
+                         unsigned long long* d_mu_hist, double* d_depth, rt_photon_trace* d_trace,
+                         hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    const size_t lds = walk_lds_bytes(cfg, false);
+    const unsigned int grid = (unsigned int)((n + kWalkBlock - 1) / kWalkBlock);
+    replay_kernel<<<grid, kWalkBlock, lds, stream>>>(cfg, tau, n, max_draws, d_xi, d_lam, d_g, d_albedo, d_scale, d_mu0,
+                                                     d_sums, d_counts, d_mu_hist, d_depth, d_trace);
+    return hipGetLastError();
+}
+
+}  // namespace rt

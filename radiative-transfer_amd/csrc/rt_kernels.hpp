@@ -1,0 +1,50 @@
+// rt_kernels.hpp -- host-visible launch interface of the walk kernels.
+#pragma once
+
+#include "rt_device.hpp"
+
+namespace rt {
+
+// How one atmosphere's photon-id range [0, n_photons) is cut up.  The cut depends only on
+// n_photons and n_slabs, never on the number of GPUs:
+//   slab s   = ids [s*slab_len, min((s+1)*slab_len, n_photons))        s = 0..n_slabs-1
+//   chunk c  = ids [slab_lo + c*chunk, ...) inside a slab               one wave walks one chunk
+// A rank owns the slabs s with s % world == rank; its chunk partials live at
+//   slot_base + j*chunks_per_slab + c   where j = (s - rank) / world.
+struct AtmPlan {
+    double tau;
+    unsigned long long n_photons;
+    unsigned long long slab_len;
+    uint32_t atm;              // index of this atmosphere in the caller's arrays
+    uint32_t chunk;            // photon ids per chunk
+    uint32_t chunks_per_slab;  // ceil(slab_len / chunk)
+    uint32_t slot_base;        // first chunk-partial slot of this atmosphere
+};
+
+struct Sweep {
+    const AtmPlan* plan;          // device, n_atm entries, heaviest atmospheres first
+    const uint32_t* item_prefix;  // device, n_atm + 1 entries: first queue index of each sorted atmosphere
+    uint32_t n_atm;
+    uint32_t n_items;
+    uint32_t rank, world;
+    uint32_t n_slabs, owned_slabs;
+};
+
+constexpr int kWalkBlock = 256;
+
+size_t walk_lds_bytes(const Cfg& cfg, bool fast);
+int walk_max_blocks_per_cu(bool fast, size_t lds_bytes);
+
+hipError_t launch_walk(const Cfg& cfg, const Sweep& sw, bool fast, int grid, hipStream_t stream,
+                       unsigned int* d_next, double* d_chunk_sums, unsigned long long* d_counts,
+                       unsigned long long* d_mu_hist, double* d_depth);
+
+hipError_t launch_slab_reduce(const Sweep& sw, const double* d_chunk_sums, double* d_slab_sums, hipStream_t stream);
+
+hipError_t launch_replay(const Cfg& cfg, double tau, long long n, int max_draws, const double* d_xi,
+                         const double* d_lam, const double* d_g, const double* d_albedo, const double* d_scale,
+                         const double* d_mu0, double* d_sums, unsigned long long* d_counts,
+                         unsigned long long* d_mu_hist, double* d_depth, rt_photon_trace* d_trace,
+                         hipStream_t stream);
+
+}  // namespace rt

@@ -1,0 +1,173 @@
+"""Thin ctypes host over the C ABI (include/rt_amd.h): one ``Engine`` per GPU.
+
+All numerical work happens in the HIP library; this module only marshals
+NumPy arrays and mirrors the argument meaning of the reference's
+``RunPhotons`` (MC code.py:620-779, Numpy_random_walk.py:280-408).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi as abi
+
+H_PLANCK = 6.6261 * (10 ** (-27))  # constants.py:10
+DEFAULT_SEED = 0x5EED2026
+
+
+class RtError(RuntimeError):
+    pass
+
+
+def _dp(a):
+    return a.ctypes.data_as(abi.c_double_p)
+
+
+def _u64p(a):
+    return a.ctypes.data_as(abi.c_u64_p)
+
+
+class SweepResult:
+    """Tallies of one sweep, one row per atmosphere (see the RT_SUM_* / RT_CNT_* enums)."""
+
+    def __init__(self, n_atm, n_mu_bins, n_depth_bins, n_slabs):
+        self.sums = np.zeros((n_atm, abi.NSUM))
+        self.counts = np.zeros((n_atm, abi.NCNT), dtype=np.uint64)
+        self.mu_hist = np.zeros((n_atm, n_mu_bins + 1), dtype=np.uint64)
+        self.depth_momentum = np.zeros((n_atm, max(n_depth_bins, 1)))
+        self.depth_energy = np.zeros((n_atm, max(n_depth_bins, 1)))
+        self.slab_sums = np.zeros((n_atm, n_slabs, abi.NSUM))
+        self.n_depth_bins = n_depth_bins
+        self._c = abi.RtTallies(_dp(self.sums), _u64p(self.counts), _u64p(self.mu_hist), _dp(self.depth_momentum),
+                                _dp(self.depth_energy), _dp(self.slab_sums))
+
+    # the reference's names (RunPhotons return values, MC code.py:779)
+    @property
+    def initial_momentum(self):
+        return self.sums[:, abi.SUM_INITIAL]
+
+    @property
+    def escaped_momentum(self):
+        return self.sums[:, abi.SUM_ESCAPED]
+
+    @property
+    def boundary_momentum(self):
+        return self.sums[:, abi.SUM_BOUNDARY]
+
+    @property
+    def scatter_count(self):
+        return self.counts[:, abi.CNT_SCATTER]
+
+    def finalize_from_slabs(self):
+        """sums = slab partials added in slab order (the same order on any GPU count)."""
+        self.sums[...] = 0.0
+        for s in range(self.slab_sums.shape[1]):
+            self.sums += self.slab_sums[:, s, :]
+
+    def momentum_fraction(self):
+        """(initial - escaped + boundary) / initial per atmosphere, runMC, MC code.py:1062."""
+        s = self.sums
+        return (s[:, abi.SUM_INITIAL] - s[:, abi.SUM_ESCAPED] + s[:, abi.SUM_BOUNDARY]) / s[:, abi.SUM_INITIAL]
+
+    def momentum_fraction_sigma(self):
+        """One-sigma statistical error of momentum_fraction (ratio estimator over photons)."""
+        s = self.sums
+        n = self.counts[:, abi.CNT_PHOTONS].astype(float)
+        m = self.momentum_fraction()
+        resid = s[:, abi.SUM_TRANSFER_SQ] - 2 * m * s[:, abi.SUM_TRANSFER_P0] + m * m * s[:, abi.SUM_P0_SQ]
+        with np.errstate(invalid="ignore", divide="ignore"):
+            var = np.maximum(resid, 0.0) * n / np.maximum(n - 1, 1) / s[:, abi.SUM_INITIAL] ** 2
+        return np.sqrt(var)
+
+
+def make_params(tau, n_photons, *, boundary="reflect", scatter="hg", order="mc", rand_mu=0, abs_only=0,
+                n_mu_bins=10, n_depth_bins=0, max_events=0, n_slabs=8, rank=0, world=1, seed=DEFAULT_SEED,
+                photon_id_base=0, monochromatic=0.0, alpha=0.3, h=H_PLANCK):
+    if boundary not in abi.BOUNDARY:
+        # the reference only prints this and carries on (MC code.py:571); here it is an error
+        raise ValueError("No valid boundary condition specified, enter a boundary condition.")
+    if scatter not in abi.SCATTER:
+        raise ValueError(f"scatter must be one of {sorted(abi.SCATTER)}")
+    tau = np.ascontiguousarray(np.atleast_1d(tau), dtype=np.float64)
+    npn = np.ascontiguousarray(np.broadcast_to(np.atleast_1d(n_photons), tau.shape), dtype=np.uint64)
+    p = abi.RtParams(len(tau), abi.BOUNDARY[boundary], abi.SCATTER[scatter], abi.ORDER[order], int(rand_mu),
+                     int(abs_only), int(n_mu_bins), int(n_depth_bins), int(max_events), int(n_slabs), int(rank),
+                     int(world), int(seed), int(photon_id_base), float(monochromatic), float(alpha), float(h),
+                     _dp(tau), _u64p(npn))
+    p._keep = (tau, npn)
+    return p
+
+
+class Engine:
+    """One GPU context.  ``Engine(device)`` fails if the HIP library or an MI355X is missing."""
+
+    def __init__(self, device=0):
+        self._lib = abi.load_library()
+        self._ctx = C.c_void_p()
+        self._check(self._lib.rt_create(C.byref(self._ctx), int(device)))
+        self.device = int(device)
+
+    def _check(self, rc):
+        if rc != 0:
+            raise RtError(f"rt_amd error {rc}: {self._lib.rt_last_error().decode()}")
+
+    def close(self):
+        if getattr(self, "_ctx", None) is not None and self._ctx:
+            self._lib.rt_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def device_info(self):
+        name = C.create_string_buffer(256)
+        cu, ws, clk = C.c_int(), C.c_int(), C.c_int()
+        self._check(self._lib.rt_device_info(self._ctx, name, 256, C.byref(cu), C.byref(ws), C.byref(clk)))
+        return dict(name=name.value.decode(), compute_units=cu.value, wave_size=ws.value, clock_khz=clk.value)
+
+    def set_tables(self, wl, g, albedo, scale, pdf=None):
+        arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in (wl, g, albedo, scale)]
+        n = len(arrs[0])
+        if any(len(a) != n for a in arrs):
+            raise ValueError("table columns differ in length")
+        pdf_a = None
+        if pdf is not None:
+            pdf_a = np.ascontiguousarray(pdf, dtype=np.float64)
+            if len(pdf_a) != n:
+                raise ValueError("pdf length differs from the table")
+        self._check(self._lib.rt_set_tables(self._ctx, n, *[_dp(a) for a in arrs],
+                                            None if pdf_a is None else _dp(pdf_a)))
+        self.n_wl = n
+
+    def run(self, params):
+        n_slabs = params.n_slabs if params.n_slabs > 0 else 8
+        res = SweepResult(params.n_atm, params.n_mu_bins, params.n_depth_bins, n_slabs)
+        self._check(self._lib.rt_run(self._ctx, C.byref(params), C.byref(res._c)))
+        return res
+
+    def run_device(self, params, slab_sums_ptr, counts_ptr, mu_hist_ptr, depth_ptr=None, stream=None):
+        """Enqueue a sweep whose results stay in caller-owned device buffers (raw addresses)."""
+        self._check(self._lib.rt_run_device(self._ctx, C.byref(params), C.c_void_p(slab_sums_ptr),
+                                            C.c_void_p(counts_ptr), C.c_void_p(mu_hist_ptr),
+                                            C.c_void_p(depth_ptr) if depth_ptr else None,
+                                            C.c_void_p(stream) if stream else None))
+
+    def replay(self, params, xi, lam, g, albedo, scale, mu0):
+        xi = np.ascontiguousarray(xi, dtype=np.float64)
+        n, max_draws = xi.shape
+        cols = [np.ascontiguousarray(a, dtype=np.float64) for a in (lam, g, albedo, scale, mu0)]
+        if any(len(c) != n for c in cols):
+            raise ValueError("per-photon arrays differ in length")
+        res = SweepResult(1, params.n_mu_bins, params.n_depth_bins, 1)
+        trace = np.zeros(n, dtype=np.dtype([("final_z", "f8"), ("final_mu", "f8"), ("fate", "i4"),
+                                            ("n_scatter", "i4"), ("n_draws", "i4"), ("pad_", "i4")]))
+        self._check(self._lib.rt_replay(self._ctx, C.byref(params), n, max_draws, _dp(xi), *[_dp(c) for c in cols],
+                                        C.byref(res._c), trace.ctypes.data_as(C.POINTER(abi.RtPhotonTrace))))
+        return res, trace
+
+    def kernel_time(self, reset=False):
+        ms, n = C.c_double(), C.c_int64()
+        self._check(self._lib.rt_kernel_time(self._ctx, C.byref(ms), C.byref(n), int(reset)))
+        return ms.value, n.value

@@ -1,0 +1,64 @@
+"""GPU parity, replay mode: the HIP walk on pre-drawn uniforms vs the reference's own outputs.
+
+tests/golden/walk_replay.npz holds what the UNMODIFIED reference functions returned
+(RunPhotons, MC code.py:620-779 and Numpy_random_walk.py:280-408) when every photon consumed
+the stream xi(id, j) rebuilt here with oracle.philox; generator: oracle/make_golden.py.
+Bar: discrete results (fates, draws consumed, scatter_count, escape histogram) exact; floating
+point within 1e-12 relative (the tolerance the north star states for replay mode).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import philox
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-12
+
+G = np.load(os.path.join(GOLDEN, "walk_replay.npz"))
+NAMES = [str(n) for n in G["names"]]
+
+
+def case(name):
+    return {k.split("/", 1)[1]: G[k] for k in G.files if k.startswith(name + "/")}
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_replay_matches_reference(rt, engine, name):
+    c = case(name)
+    n = int(c["n"])
+    order = str(c["order"])
+    max_draws = int(c["ref_draws"].max())
+    xi = philox.walk_matrix(n, max_draws, 0, int(c["seed"]))
+    prm = rt.make_params(float(c["tau"]), n, boundary=str(c["boundary"]), scatter=str(c["scatter"]), order=order,
+                         abs_only=int(c["abs_only"]), h=(1.0 if order == "gray" else rt.H_PLANCK), n_mu_bins=10)
+    res, tr = engine.replay(prm, xi, c["lam"], c["g"], c["albedo"], c["scale"], c["mu0"])
+    A = rt._abi
+    assert np.array_equal(tr["fate"], c["ref_fate"])
+    assert np.array_equal(tr["n_draws"], c["ref_draws"])
+    np.testing.assert_allclose(tr["final_mu"], c["ref_final_mu"], rtol=RTOL, atol=1e-15)
+    np.testing.assert_allclose(tr["final_z"], c["ref_final_z"], rtol=RTOL, atol=1e-15)
+    s = res.sums[0]
+    np.testing.assert_allclose(s[A.SUM_INITIAL], float(c["ref_initial_momentum"]), rtol=RTOL)
+    np.testing.assert_allclose(s[A.SUM_ESCAPED], float(c["ref_escaped_momentum"]), rtol=RTOL)
+    np.testing.assert_allclose(s[A.SUM_BOUNDARY], float(c["ref_boundary_momentum"]), rtol=RTOL,
+                               atol=1e-12 * abs(float(c["ref_initial_momentum"])))
+    if int(c["ref_scatter_count"]) >= 0:
+        assert int(res.counts[0, A.CNT_SCATTER]) == int(c["ref_scatter_count"])
+    # escape-cosine population the reference returns as escaped_mu
+    ref_hist = np.bincount(np.minimum(np.floor(10 * c["ref_escaped_mu"]).astype(int), 10), minlength=11)
+    assert np.array_equal(res.mu_hist[0], ref_hist)
+    assert int(res.counts[0, A.CNT_PHOTONS]) == n
+    assert int(res.counts[0, A.CNT_GUARD]) == 0
+
+
+def test_replay_guard_on_short_stream(rt, engine):
+    """A photon whose stream runs out is reported as guard-killed, not looped on."""
+    n = 256
+    xi = philox.walk_matrix(n, 3, 0, 5)
+    prm = rt.make_params(50.0, n, h=1.0)
+    res, tr = engine.replay(prm, xi, np.ones(n), np.full(n, 0.5), np.ones(n), np.ones(n), np.ones(n))
+    assert int(res.counts[0, rt._abi.CNT_GUARD]) == int((tr["fate"] == rt._abi.FATE_GUARD).sum()) > 0

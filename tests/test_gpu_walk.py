@@ -1,0 +1,123 @@
+"""GPU parity, production mode: Philox-driven sweep vs the CPU oracle on the same streams.
+
+The oracle (oracle/rt_oracle.c, pinned to the reference by tests/golden/walk_replay.npz) uses the
+same counter layout, so the comparison is photon population by photon population: integer tallies
+exact, floating-point sums to 1e-12 relative.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-12
+
+
+def small_table(n=64):
+    wl = np.round(np.linspace(0.1, 1.0, n), 4)
+    g = np.linspace(0.3, 0.8, n) * np.where(np.arange(n) % 7 == 0, -1, 1)
+    alb = np.linspace(0.4, 0.95, n)
+    scale = np.linspace(2.0, 0.5, n)
+    pdf = (np.linspace(1.0, 0.1, n) ** 2) / n
+    pdf[5:9] = 0.0
+    return wl, g, alb, scale, pdf
+
+
+def compare(res, ref, A, nd=0):
+    assert np.array_equal(res.counts, ref.counts)
+    assert np.array_equal(res.mu_hist, ref.mu_hist)
+    scale = np.abs(ref.sums[:, [A.SUM_INITIAL]])
+    np.testing.assert_allclose(res.sums, ref.sums, rtol=RTOL, atol=0)
+    np.testing.assert_allclose(res.slab_sums, ref.slab_sums, rtol=RTOL, atol=0)
+    if nd:
+        np.testing.assert_allclose(res.depth_momentum, ref.depth_momentum, rtol=1e-11, atol=1e-13 * scale)
+        np.testing.assert_allclose(res.depth_energy, ref.depth_energy, rtol=1e-11, atol=1e-13 * scale)
+
+
+@pytest.mark.parametrize("boundary", ["reflect", "absorb", "reemit"])
+@pytest.mark.parametrize("scatter", ["hg", "iso"])
+def test_sweep_matches_oracle(rt, engine, c_oracle, boundary, scatter):
+    wl, g, alb, scale, pdf = small_table()
+    engine.set_tables(wl, g, alb, scale, pdf)
+    tau = np.array([1e-3, 0.3, 2.0, 20.0])
+    kw = dict(boundary=boundary, scatter=scatter, n_mu_bins=10, rand_mu=(boundary == "reemit"))
+    res = engine.run(rt.make_params(tau, 6000, **kw))
+    ref = c_oracle.run(c_oracle.make_params(tau, 6000, **kw), wl, g, alb, scale, pdf)
+    compare(res, ref, rt._abi)
+
+
+def test_depth_bins_and_identities(rt, engine, c_oracle):
+    A = rt._abi
+    wl, g, alb, scale, pdf = small_table()
+    engine.set_tables(wl, g, alb, scale, pdf)
+    tau = np.array([0.5, 5.0])
+    kw = dict(n_mu_bins=20, n_depth_bins=16)
+    res = engine.run(rt.make_params(tau, 20000, **kw))
+    ref = c_oracle.run(c_oracle.make_params(tau, 20000, **kw), wl, g, alb, scale, pdf)
+    compare(res, ref, A, nd=16)
+    s = res.sums
+    # depth bins add up to the dust momentum; energy bins to the absorbed energy
+    np.testing.assert_allclose(res.depth_momentum.sum(1), s[:, A.SUM_DUST_MOMENTUM], rtol=1e-10)
+    np.testing.assert_allclose(res.depth_energy.sum(1), s[:, A.SUM_ABSORBED_ENERGY], rtol=1e-10)
+    # two estimators of the transferred momentum agree (MC code.py:648-650, :728-729, :773-776):
+    # initial = escaped(all) + dust + boundary deposit, and a reflection deposits -2*boundary_momentum
+    lhs = s[:, A.SUM_INITIAL]
+    rhs = s[:, A.SUM_ESCAPED] + s[:, A.SUM_ESCAPED_UNCOUNTED] + s[:, A.SUM_DUST_MOMENTUM] - 2 * s[:, A.SUM_BOUNDARY]
+    np.testing.assert_allclose(lhs, rhs, rtol=1e-10)
+
+
+def test_gray_order_and_monochromatic(rt, engine, c_oracle):
+    engine.set_tables([1.0], [0.5], [0.9], [1.0])
+    tau = np.logspace(-2, 2, 10)
+    kw = dict(order="gray", h=1.0, monochromatic=1.0, n_mu_bins=10)
+    res = engine.run(rt.make_params(tau, 10000, **kw))
+    ref = c_oracle.run(c_oracle.make_params(tau, 10000, **kw), [1.0], [0.5], [0.9], [1.0])
+    compare(res, ref, rt._abi)
+
+
+def test_draine_phase_function(rt, engine, c_oracle):
+    engine.set_tables([1.0], [0.5], [0.9], [1.0])
+    tau = np.array([1.0, 3.0])
+    kw = dict(order="gray", h=1.0, scatter="draine", alpha=0.3, n_mu_bins=10)
+    res = engine.run(rt.make_params(tau, 8000, **kw))
+    ref = c_oracle.run(c_oracle.make_params(tau, 8000, **kw), [1.0], [0.5], [0.9], [1.0])
+    compare(res, ref, rt._abi)
+
+
+def test_result_independent_of_gpu_count(rt, engine):
+    """Walking the slabs as 1, 2, 4 or 8 ranks gives bitwise the same tallies after the slab sum."""
+    wl, g, alb, scale, pdf = small_table()
+    engine.set_tables(wl, g, alb, scale, pdf)
+    tau = np.array([0.2, 3.0])
+    base = engine.run(rt.make_params(tau, 50000))
+    for world in (2, 4, 8):
+        slab = np.zeros_like(base.slab_sums)
+        counts = np.zeros_like(base.counts)
+        hist = np.zeros_like(base.mu_hist)
+        for rank in range(world):
+            r = engine.run(rt.make_params(tau, 50000, rank=rank, world=world))
+            slab += r.slab_sums  # what an all-reduce(sum) of disjoint non-zero entries does
+            counts += r.counts
+            hist += r.mu_hist
+        assert np.array_equal(slab, base.slab_sums)
+        assert np.array_equal(counts, base.counts)
+        assert np.array_equal(hist, base.mu_hist)
+
+
+def test_rerun_is_bitwise_reproducible(rt, engine):
+    wl, g, alb, scale, pdf = small_table()
+    engine.set_tables(wl, g, alb, scale, pdf)
+    prm = rt.make_params(np.array([1.0, 8.0]), 300000)
+    a = engine.run(prm)
+    b = engine.run(prm)
+    assert np.array_equal(a.sums, b.sums) and np.array_equal(a.counts, b.counts)
+
+
+def test_errors(rt, engine):
+    engine.set_tables([0.5], [0.5], [0.5], [1.0])
+    with pytest.raises(rt.RtError):
+        engine.run(rt.make_params(1.0, 100, monochromatic=0.7))
+    with pytest.raises(ValueError):
+        rt.make_params(1.0, 100, boundary="bounce")
+    with pytest.raises(rt.RtError):
+        engine.run(rt.make_params(1.0, 100, scatter="draine"))
+    with pytest.raises(rt.RtError):
+        engine.run(rt.make_params(1.0, 100, world=3))
