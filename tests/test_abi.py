@@ -1,0 +1,50 @@
+"""The C-ABI library loads and exports every symbol include/rt_amd.h declares (no GPU needed)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "rt_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rt_[a-z_]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported(rt):
+    lib = rt._abi.load_library()
+    names = declared_functions()
+    assert set(names) == set(rt._abi.EXPORTS)
+    for n in names:
+        assert getattr(lib, n) is not None
+    assert lib.rt_abi_version() == rt._abi.RT_ABI_VERSION
+
+
+def test_struct_layout_matches_header(rt):
+    A = rt._abi
+    # 12 int32, 2 uint64, 3 doubles, 2 pointers -- no padding surprises
+    assert ctypes.sizeof(A.RtParams) == 12 * 4 + 2 * 8 + 3 * 8 + 2 * 8
+    assert ctypes.sizeof(A.RtTallies) == 6 * 8
+    assert ctypes.sizeof(A.RtPhotonTrace) == 32
+    assert A.RtParams.seed.offset == 48 and A.RtParams.tau_atm.offset == 88
+
+
+def test_no_cpu_fallback(rt):
+    """Without a GPU the engine must refuse to start rather than compute on the host."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(rt.RtError, match="no HIP device|no CPU fallback|failed"):
+        rt.Engine(0)
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "radiative-transfer_amd")
+    for base, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                text = open(os.path.join(base, f)).read()
+                assert "oracle" not in text.replace("# oracle", ""), f
