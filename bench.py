@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""Benchmark of the dust photon random walk on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One *step* is one full sweep of the headline configuration: 100 atmospheres
+(tau = logspace(-3, 2, 100)) x 2e7 photons each through the Sil/Gra/SiC dust mix, tables and
+emission law resident in HBM before the timed region.  For N > 1 (one process per GPU, launched by
+torch.distributed.run) every rank walks its own slabs of the photon-id range -- per-GPU work is
+fixed, so the global run has N x 2e7 photons per atmosphere ("weak" scaling) -- and the only
+collective is one all-reduce (RCCL) of the slab tallies per step, inside the timed region.
+
+Prints ONE JSON line on rank 0.  `value` = scatter events of all ranks / wall time of the K steps
+(max over ranks).  `roofline` is for the walk kernel: algorithmic FP64 operations per launch
+(35 per scatter event, as the reference writes them: MC code.py:427-441, 493-508, 576-618) divided by
+the kernel's average duration measured with HIP events on its stream, against the FP64 vector peak.
+`cpu_baseline` times the NumPy restatement of the reference loop (oracle/numpy_walk.py, pinned to
+the reference by tests/golden) on a bounded sample of the same workload on this host.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FP64_OPS_PER_EVENT = 35          # algorithmic FP64 operations of one scatter event
+FP64_VECTOR_PEAK_TFLOPS = 78.6   # MI355X: 256 CU x 128 FLOP/clk x 2.4 GHz
+
+
+def cpu_baseline(cfg, n_cpu, seconds_cap=40.0):
+    """NumPy restatement of RunPhotons over the same tau list with n_cpu photons per atmosphere."""
+    from oracle import numpy_walk as nw
+    rs = np.random.RandomState(12345)
+    w = np.clip(np.nan_to_num(cfg["pdf"]), 0, 1)
+    cdf = np.cumsum(w)
+    events, t0, done = 0, time.perf_counter(), 0
+    for tau in cfg["tau_list"]:
+        idx = np.minimum(np.searchsorted(cdf, rs.rand(n_cpu) * cdf[-1], side="right"), len(cdf) - 1)
+        r = nw.run_photons(tau, cfg["wl"][idx], cfg["g"][idx], cfg["albedo"][idx], cfg["scale"][idx], np.ones(n_cpu),
+                           boundary=cfg["boundary"], scatter=cfg["scatter"], order=cfg["order"],
+                           stream=nw.GlobalStream(rs), h=cfg["h"])
+        events += r["scatter_count"]
+        done += 1
+        if time.perf_counter() - t0 > seconds_cap:
+            break
+    dt = time.perf_counter() - t0
+    return dict(value=events / dt, unit="scatter events/s", cores=1, kind="port",
+                sample=f"{n_cpu} photons/atmosphere x {done} of {len(cfg['tau_list'])} atmospheres of the same sweep "
+                       f"({events} events in {dt:.1f} s, oracle/numpy_walk.py, 1 process)")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="mix_2e7")
+    ap.add_argument("--photons", type=int, default=0, help="photons per atmosphere per GPU (0 = the workload's own)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--cpu-photons", type=int, default=100000)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; there is no CPU path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    rt = importlib.import_module("radiative-transfer_amd")
+    workloads = importlib.import_module("radiative-transfer_amd.workloads")
+    A = rt._abi
+    cfg = workloads.WORKLOADS[args.workload]()
+    per_gpu = args.photons or cfg["n_photons"]
+    n_slabs = 8
+    total_photons = per_gpu * world if args.scaling == "weak" else per_gpu
+    tau = cfg["tau_list"]
+    n_atm = len(tau)
+
+    eng = rt.Engine(local_rank)
+    eng.set_tables(cfg["wl"], cfg["g"], cfg["albedo"], cfg["scale"], cfg["pdf"])
+    dev = torch.device("cuda", local_rank)
+    slab = torch.zeros(n_atm * n_slabs * A.NSUM, dtype=torch.float64, device=dev)
+    counts = torch.zeros(n_atm * A.NCNT, dtype=torch.int64, device=dev)
+    hist = torch.zeros(n_atm * 11, dtype=torch.int64, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step(i):
+        prm = rt.make_params(tau, total_photons, boundary=cfg["boundary"], scatter=cfg["scatter"], order=cfg["order"],
+                             n_mu_bins=10, n_slabs=n_slabs, rank=rank, world=world, h=cfg["h"],
+                             monochromatic=cfg["monochromatic"], photon_id_base=i * total_photons)
+        eng.run_device(prm, slab.data_ptr(), counts.data_ptr(), hist.data_ptr(), None, stream)
+        if world > 1:
+            # every slab entry is non-zero on exactly one rank, so the sum is exact and order-free
+            dist.all_reduce(slab)
+            dist.all_reduce(counts)
+            dist.all_reduce(hist)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    eng.kernel_time(reset=True)
+    events = 0
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+        # counts are read after the timed region; accumulate on device
+        if i == 0:
+            ev_dev = counts.view(n_atm, A.NCNT)[:, A.CNT_SCATTER].sum()
+        else:
+            ev_dev = ev_dev + counts.view(n_atm, A.NCNT)[:, A.CNT_SCATTER].sum()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    events = int(ev_dev.item())          # after the all-reduce this is the whole job's count
+    kernel_ms, launches = eng.kernel_time()
+    last = counts.view(n_atm, A.NCNT).cpu().numpy()
+    events_last = int(last[:, A.CNT_SCATTER].sum())
+    events_rank_last = events_last / world if world > 1 else events_last  # equal shares by construction
+
+    if rank == 0:
+        value = events / dt
+        achieved = events_rank_last * FP64_OPS_PER_EVENT / (kernel_ms * 1e-3) / 1e12
+        out = {
+            "metric": "photon-scatter events/sec", "value": value, "unit": "events/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"{cfg['name']}: {n_atm} atmospheres tau=logspace(-3,2,100) x {per_gpu:.3g} photons "
+                                   f"per atmosphere per GPU, Sil/Gra/SiC MRN mix, Planck(3e4 K) emission, reflect + hg",
+                       "photons_per_atmosphere_global": total_photons, "photon_histories_per_step": int(last[:, A.CNT_PHOTONS].sum()),
+                       "flights_per_step": int(last[:, A.CNT_FLIGHTS].sum()), "events_per_step": events_last,
+                       "parallelism": f"photon-id slabs over {world} GPU(s), 1 all-reduce of tallies per step"},
+            "photon_histories_per_s": float(last[:, A.CNT_PHOTONS].sum()) * args.steps / dt,
+            "roofline": {"bound": "valu_fp64", "achieved": achieved, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / FP64_VECTOR_PEAK_TFLOPS, "traffic": None,
+                         "kernel": "walk_kernel", "kernel_avg_ms": kernel_ms, "kernel_launches": launches,
+                         "flop_per_event": FP64_OPS_PER_EVENT},
+        }
+        if world == 1 and not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_photons)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -130,11 +130,14 @@ def replay_reference(order, case):
                 final_z=final_z, draws=st["ctr"].copy())
 
 
-def make_case(name, order, n, tau, boundary, scatter, seed, abs_only=0, rand_mu0=False, gray_albedo=0.9, gray_g=0.5):
+def make_case(name, order, n, tau, boundary, scatter, seed, abs_only=0, rand_mu0=False, gray_albedo=0.9, gray_g=0.5,
+              tiny_g=False):
     rng = np.random.default_rng(seed)
     if order == "mc":
         lam = np.round(rng.uniform(0.1, 2.0, n), 4)
         g = rng.uniform(0.05, 0.95, n) * np.where(rng.random(n) < 0.15, -1.0, 1.0)
+        if tiny_g:  # number-weighted MRN averages give g as small as 1e-7 (cancellation in the HG formula)
+            g = 10.0 ** rng.uniform(-7, -2, n)
         alb = rng.uniform(0.2, 0.95, n)
         scale = rng.uniform(0.3, 3.0, n)
     else:
@@ -156,7 +159,8 @@ REPLAY_CASES = [
     make_case("mc_reflect_hg_tau1em3", "mc", 3000, 1e-3, "reflect", "hg", 108),
     make_case("mc_reemit_hg_tau4_randmu", "mc", 2000, 4.0, "reemit", "hg", 109, rand_mu0=True),
     make_case("gray_reflect_hg_tau3", "gray", 3000, 3.0, "reflect", "hg", 201, gray_albedo=0.9, gray_g=0.5),
-    make_case("gray_reemit_iso_tau10", "gray", 2000, 10.0, "reemit", "iso", 202, gray_albedo=1.0, gray_g=0.0),
+    make_case("mc_reflect_hg_tau2_tiny_g", "mc", 3000, 2.0, "reflect", "hg", 110, tiny_g=True),
+    make_case("gray_reemit_iso_tau10", "gray", 600, 10.0, "reemit", "iso", 202, gray_albedo=1.0, gray_g=0.0),
     make_case("gray_absorb_hg_tau1", "gray", 3000, 1.0, "absorb", "hg", 203, gray_albedo=0.7, gray_g=-0.6),
     make_case("gray_reflect_hg_g0_tau2", "gray", 3000, 2.0, "reflect", "hg", 204, gray_albedo=0.8, gray_g=0.0),
 ]

@@ -80,6 +80,8 @@ struct rt_ctx {
     // result staging for rt_run / rt_replay
     DevBuf<double> d_slab_sums, d_depth, d_sums;
     DevBuf<unsigned long long> d_counts, d_mu_hist;
+    int blocks_per_cu[2] = {0, 0};  // occupancy of walk_kernel<false/true> for blocks_lds bytes of LDS
+    size_t blocks_lds[2] = {0, 0};
     // kernel timing
     std::vector<EventPair> events;
     size_t events_used = 0;
@@ -301,7 +303,7 @@ int rt_run_device(rt_ctx* ctx, const rt_params* p, void* d_slab_sums, void* d_co
     if (p->rank < 0 || p->rank >= world) return fail(RT_ERR_INVALID, "rank %d not in [0,%d)", p->rank, world);
     if (n_slabs % world != 0) return fail(RT_ERR_INVALID, "n_slabs (%d) must be a multiple of world (%d)", n_slabs, world);
     RT_HIP(hipSetDevice(ctx->device));
-    hipStream_t stream = stream_v ? (hipStream_t)stream_v : ctx->stream;
+    hipStream_t stream = (hipStream_t)stream_v;  // NULL is the (legacy) default stream
 
     rt::Cfg cfg = make_cfg(ctx, p);
     if (p->monochromatic_wl != 0.0) {
@@ -381,7 +383,12 @@ int rt_run_device(rt_ctx* ctx, const rt_params* p, void* d_slab_sums, void* d_co
                       p->scatter == RT_SCATTER_HG && p->n_depth_bins == 0 && !p->abs_only;
     const size_t lds = rt::walk_lds_bytes(cfg, fast);
     if (lds > 64 * 1024) return fail(RT_ERR_LIMIT, "histogram bins need %zu bytes of LDS per block (max 65536)", lds);
-    const int per_cu = rt::walk_max_blocks_per_cu(fast, lds);
+    int& cached = ctx->blocks_per_cu[fast ? 1 : 0];
+    if (cached <= 0 || ctx->blocks_lds[fast ? 1 : 0] != lds) {
+        cached = rt::walk_max_blocks_per_cu(fast, lds);
+        ctx->blocks_lds[fast ? 1 : 0] = lds;
+    }
+    const int per_cu = cached;
     long long grid = (long long)ctx->prop.multiProcessorCount * per_cu;
     const long long need = ((long long)items + 3) / 4;
     if (grid > need) grid = need;
