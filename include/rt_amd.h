@@ -177,6 +177,10 @@ int rt_replay(rt_ctx* ctx, const rt_params* p, int64_t n, int32_t max_draws, con
               const double* lambda, const double* g, const double* albedo, const double* scale,
               const double* mu0, rt_tallies* out, rt_photon_trace* per_photon);
 
+/* Test hook (no reference counterpart): applies the kernels' own fp64 ln(u) and cos(2*pi*u) to n host
+ * values u in [0,1) so that their accuracy can be checked against a host math library. */
+int rt_selftest_math(rt_ctx* ctx, int64_t n, const double* u, double* out_log, double* out_cos);
+
 /* Average kernel time (ms) and launch count of the walk kernel since the last call with reset != 0,
  * measured with HIP events on the stream the kernel ran on. */
 int rt_kernel_time(rt_ctx* ctx, double* avg_ms, int64_t* launches, int reset);

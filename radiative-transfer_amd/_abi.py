@@ -54,7 +54,7 @@ class RtPhotonTrace(C.Structure):
 
 
 EXPORTS = ["rt_abi_version", "rt_last_error", "rt_create", "rt_destroy", "rt_device_info", "rt_set_tables",
-           "rt_run", "rt_run_device", "rt_replay", "rt_kernel_time"]
+           "rt_run", "rt_run_device", "rt_replay", "rt_kernel_time", "rt_selftest_math"]
 
 _lib = None
 
@@ -80,6 +80,7 @@ def load_library(path=None):
     lib.rt_run_device.argtypes = [vp, C.POINTER(RtParams), vp, vp, vp, vp, vp]
     lib.rt_replay.argtypes = [vp, C.POINTER(RtParams), C.c_int64, C.c_int32, c_double_p, c_double_p, c_double_p,
                               c_double_p, c_double_p, c_double_p, C.POINTER(RtTallies), C.POINTER(RtPhotonTrace)]
+    lib.rt_selftest_math.argtypes = [vp, C.c_int64, c_double_p, c_double_p, c_double_p]
     lib.rt_kernel_time.argtypes = [vp, c_double_p, C.POINTER(C.c_int64), C.c_int]
     for name in EXPORTS:
         getattr(lib, name)  # AttributeError if an entry point is missing

@@ -72,6 +72,7 @@ struct rt_ctx {
     DevBuf<rt::TableRec> d_rec;
     DevBuf<double> d_cdf;
     DevBuf<int32_t> d_guide;
+    DevBuf<rt::LogTableEntry> d_log_table;
     // sweep workspace
     DevBuf<rt::AtmPlan> d_plan;
     DevBuf<uint32_t> d_prefix;
@@ -131,6 +132,7 @@ rt::Cfg make_cfg(const rt_ctx* ctx, const rt_params* p) {
     c.guide_k = ctx->guide_k;
     c.mono_index = -1;
     c.total = ctx->total;
+    c.log_table = ctx->d_log_table.p;
     return c;
 }
 
@@ -207,6 +209,20 @@ int rt_create(rt_ctx** out, int device_id) {
         delete ctx;
         return fail(RT_ERR_DEVICE, "hipStreamCreate: %s", hipGetErrorString(e));
     }
+    // logarithm table for the kernels' ln(): c_j = 1 + (j + 1/2)/128, inv_c = fl(1/c_j), l = -ln(inv_c)
+    std::vector<rt::LogTableEntry> tab(rt::kLogTableEntries);
+    for (int j = 0; j < rt::kLogTableEntries; ++j) {
+        const double c = 1.0 + ((double)j + 0.5) / (double)rt::kLogTableEntries;
+        tab[j].inv_c = 1.0 / c;
+        tab[j].l = (double)(-logl((long double)tab[j].inv_c));
+    }
+    e = ctx->d_log_table.reserve(tab.size());
+    if (e == hipSuccess)
+        e = hipMemcpy(ctx->d_log_table.p, tab.data(), sizeof(rt::LogTableEntry) * tab.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        rt_destroy(ctx);
+        return fail(RT_ERR_DEVICE, "log table upload: %s", hipGetErrorString(e));
+    }
     *out = ctx;
     return RT_OK;
 }
@@ -222,6 +238,7 @@ int rt_destroy(rt_ctx* ctx) {
     ctx->d_rec.release();
     ctx->d_cdf.release();
     ctx->d_guide.release();
+    ctx->d_log_table.release();
     ctx->d_plan.release();
     ctx->d_prefix.release();
     ctx->d_chunk_sums.release();
@@ -256,7 +273,7 @@ int rt_set_tables(rt_ctx* ctx, int32_t n_wl, const double* wl, const double* g, 
     double acc = 0.0;
     int last = -1;
     for (int i = 0; i < n_wl; ++i) {
-        rec[i] = {wl[i], g[i], albedo[i], scale[i]};
+        rec[i] = {wl[i], 1.0 / wl[i], g[i], albedo[i], scale[i], 1.0 / (2.0 * g[i]), 1.0 + g[i] * g[i], 1.0 - g[i] * g[i]};
         double p = pdf ? pdf[i] : 1.0;
         if (!(p > 0.0)) p = 0.0;  // also maps NaN to 0
         if (p > 1.0) p = 1.0;     // AcceptReject accepts with probability min(PDF, 1)
@@ -507,6 +524,23 @@ int rt_replay(rt_ctx* ctx, const rt_params* p, int64_t n, int32_t max_draws, con
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     cleanup();
     if (e != hipSuccess) return fail(RT_ERR_DEVICE, "replay failed: %s", hipGetErrorString(e));
+    return RT_OK;
+}
+
+int rt_selftest_math(rt_ctx* ctx, int64_t n, const double* u, double* out_log, double* out_cos) {
+    if (!ctx) return fail(RT_ERR_INVALID, "ctx is NULL");
+    if (n < 0 || (n > 0 && (!u || !out_log || !out_cos))) return fail(RT_ERR_INVALID, "bad argument");
+    if (n == 0) return RT_OK;
+    RT_HIP(hipSetDevice(ctx->device));
+    DevBuf<double> d;
+    hipError_t e = d.reserve(3 * (size_t)n);
+    if (e == hipSuccess) e = hipMemcpyAsync(d.p, u, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = rt::launch_selftest_math(ctx->d_log_table.p, (long long)n, d.p, d.p + n, d.p + 2 * n, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out_log, d.p + n, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out_cos, d.p + 2 * n, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    d.release();
+    if (e != hipSuccess) return fail(RT_ERR_DEVICE, "selftest failed: %s", hipGetErrorString(e));
     return RT_OK;
 }
 

@@ -22,6 +22,7 @@
 #include <stdint.h>
 
 #include "../../include/rt_amd.h"
+#include "rt_math.hpp"
 
 namespace rt {
 
@@ -61,9 +62,12 @@ __device__ __forceinline__ double u53(uint32_t a, uint32_t b) {
 // ---------------------------------------------------------------------------
 // Run configuration (wave-uniform; passed by value as a kernel argument).
 // ---------------------------------------------------------------------------
-struct TableRec {  // one wavelength: what CreatePhotons copies into a photon row
-    double lam, g, albedo, scale;
+struct TableRec {  // one wavelength: what CreatePhotons copies into a photon row, plus the
+                   // per-photon constants of GetZMomentum and HGScatter, precomputed on the host
+                   // with the reference's own expressions (1/lambda, 1/(2*g), 1+g**2, 1-g**2)
+    double lam, inv_lam, g, albedo, scale, inv2g, opg2, omg2;
 };
+static_assert(sizeof(TableRec) == 64, "one table record per 64-byte line");
 
 struct Cfg {
     int32_t boundary, scatter, order, rand_mu, abs_only;
@@ -77,6 +81,7 @@ struct Cfg {
     const int32_t* guide;  // guide[k] = first index whose cdf exceeds (k/K)*total, K+1 entries
     int32_t n_wl, guide_k, mono_index;
     double total;
+    const LogTableEntry* log_table;  // kLogTableEntries entries in global memory (copied to LDS per workgroup)
 };
 
 struct Photon {
@@ -96,11 +101,13 @@ struct Acc {
     }
 };
 
-// Wave-private histograms in LDS (pointers are null when the tally is off).
+// Wave-private histograms in LDS (pointers are null when the tally is off) and the
+// workgroup's copy of the logarithm table.
 struct Hist {
     uint32_t* mu;
     double* depth_mom;
     double* depth_en;
+    const LogTableEntry* log_table;
 };
 
 // ---------------------------------------------------------------------------
@@ -179,12 +186,24 @@ __device__ __forceinline__ void set_constants(const Cfg& cfg, double tau, double
     ph.mu = mu0;
 }
 
+__device__ __forceinline__ void set_constants(const Cfg& cfg, double tau, const TableRec& r, double mu0, Photon& ph) {
+    ph.wh = (cfg.order == RT_ORDER_GRAY ? r.lam : r.inv_lam) * cfg.h;
+    ph.g = r.g;
+    ph.albedo = r.albedo;
+    ph.zmax = tau * r.scale;
+    ph.inv2g = r.inv2g;
+    ph.opg2 = r.opg2;
+    ph.omg2 = r.omg2;
+    ph.z = 0.0;
+    ph.mu = mu0;
+}
+
 __device__ __forceinline__ void emit_from_table(const Cfg& cfg, double tau, PhiloxSrc& src, Photon& ph) {
     double ua, ub;
     src.emit_pair(ua, ub);
     const int i = sample_index(cfg, ua);
     const TableRec r = cfg.rec[i];
-    set_constants(cfg, tau, r.lam, r.g, r.albedo, r.scale, cfg.rand_mu ? ub : 1.0, ph);
+    set_constants(cfg, tau, r, cfg.rand_mu ? ub : 1.0, ph);
 }
 
 __device__ __forceinline__ int depth_bin(const Cfg& cfg, const Photon& ph) {
@@ -200,29 +219,28 @@ __device__ __forceinline__ double draine_pdf(double g, double alpha, double m) {
 }
 
 // ---------------------------------------------------------------------------
-// One loop iteration of one photon.  Returns 0 while the photon is alive,
-// otherwise its RT_FATE_*.  FAST fixes (RT_ORDER_MC, reflect, hg, no depth
-// bins, abs_only off) at compile time; the generic form reads cfg.
-// `reemit` is called when a photon is re-emitted at the lower boundary.
+// One loop iteration of one photon, in two halves.
+//   fly()      TakeStep, escape / boundary / escape tests, Absorb.  Returns the photon's
+//              RT_FATE_* if its history ends here, 0 if it goes on to scatter.
+//   scatter()  HGScatter / IsoScatter / Draine sampling + RotateIntoLabFrame.  Returns 0, or
+//              RT_FATE_GUARD when a bounded stream runs out.
+// FAST fixes (RT_ORDER_MC, reflect, hg, no depth bins, abs_only off) at compile time; the
+// generic form reads cfg.  `reemit` is called when a photon is re-emitted at the lower boundary.
 // ---------------------------------------------------------------------------
-template <bool FAST, class Src, class Reemit>
-__device__ __forceinline__ int flight(const Cfg& cfg, Photon& ph, Src& src, Acc& acc, const Hist& hist,
-                                      Reemit&& reemit) {
+template <bool FAST, class Reemit>
+__device__ __forceinline__ int fly(const Cfg& cfg, Photon& ph, double u_step, double u_abs, int avail, bool bounded,
+                                   Acc& acc, const Hist& hist, Reemit&& reemit, int& n_used) {
     const bool gray = FAST ? false : cfg.order == RT_ORDER_GRAY;
     const int boundary = FAST ? (int)RT_BOUNDARY_REFLECT : cfg.boundary;
-    const int scatter = FAST ? (int)RT_SCATTER_HG : cfg.scatter;
     const bool depth = FAST ? false : cfg.n_depth_bins > 0;
 
-    double u_step, u_abs;
-    if (ph.iter >= (uint32_t)cfg.max_events) return RT_FATE_GUARD;
-    const int avail = src.pair(u_step, u_abs);
-    if (Src::kBounded && avail < 1) return RT_FATE_GUARD;
+    if (bounded && avail < 1) return RT_FATE_GUARD;
     ph.iter++;
     acc.c[RT_CNT_FLIGHTS]++;
-    src.used(1);
+    n_used += 1;
 
     // TakeStep
-    ph.z += -log(u_step) * ph.mu;
+    ph.z += -log_unit(u_step, hist.log_table) * ph.mu;
 
     if (!gray && ph.z > ph.zmax) {  // first escape test: momentum tallied
         ph.e1 = ph.mu * ph.wh;
@@ -255,8 +273,8 @@ __device__ __forceinline__ int flight(const Cfg& cfg, Photon& ph, Src& src, Acc&
     }
 
     // Absorb
-    if (Src::kBounded && avail < 2) return RT_FATE_GUARD;
-    src.used(1);
+    if (bounded && avail < 2) return RT_FATE_GUARD;
+    n_used += 1;
     const bool absorbed = (!FAST && cfg.abs_only) ? (u_abs > 0.0) : (u_abs > ph.albedo);
     if (absorbed) {
         const double pa = ph.mu * ph.wh;
@@ -269,21 +287,26 @@ __device__ __forceinline__ int flight(const Cfg& cfg, Photon& ph, Src& src, Acc&
         }
         return RT_FATE_ABSORBED;
     }
+    return 0;
+}
 
-    // Scatter
-    double u_phi, u_s;
-    const int avail2 = src.pair(u_phi, u_s);
+template <bool FAST, class Src>
+__device__ __forceinline__ int scatter(const Cfg& cfg, Photon& ph, Src& src, double u_phi, double u_s, int avail2,
+                                       Acc& acc, const Hist& hist) {
+    const bool gray = FAST ? false : cfg.order == RT_ORDER_GRAY;
+    const int law = FAST ? (int)RT_SCATTER_HG : cfg.scatter;
+    const bool depth = FAST ? false : cfg.n_depth_bins > 0;
     if (Src::kBounded && avail2 < 2) return RT_FATE_GUARD;
     src.used(2);
     const double mu_old = ph.mu;
     bool iso = false;
     if (!FAST) {
-        if (scatter == RT_SCATTER_ISO) iso = gray ? true : (ph.iter == 1u);
-        if (gray && scatter == RT_SCATTER_HG && ph.g == 0.0) iso = true;
+        if (law == RT_SCATTER_ISO) iso = gray ? true : (ph.iter == 1u);
+        if (gray && law == RT_SCATTER_HG && ph.g == 0.0) iso = true;
     }
     double mu_prime;
     bool direct = false;
-    if (!FAST && scatter == RT_SCATTER_DRAINE && !iso) {
+    if (!FAST && law == RT_SCATTER_DRAINE && !iso) {
         mu_prime = 0.0;
         bool ok = false;
         for (;;) {  // rejection sampling of the Draine phase function, one pair (y, candidate) per try
@@ -316,8 +339,7 @@ __device__ __forceinline__ int flight(const Cfg& cfg, Photon& ph, Src& src, Acc&
     } else if (mu_old == -1.0) {
         mu_new = -mu_prime;
     } else {
-        const double phi = kTwoPi * u_phi;
-        mu_new = -sqrt(1.0 - mu_old * mu_old) * sqrt(1.0 - mu_prime * mu_prime) * cos(phi) + mu_old * mu_prime;
+        mu_new = -sqrt((1.0 - mu_old * mu_old) * (1.0 - mu_prime * mu_prime)) * cos_2pi(u_phi) + mu_old * mu_prime;
     }
     ph.mu = mu_new;
     ph.n_scatter++;
@@ -326,6 +348,22 @@ __device__ __forceinline__ int flight(const Cfg& cfg, Photon& ph, Src& src, Acc&
     acc.s[RT_SUM_DUST_MOMENTUM] += dp;
     if (depth) atomicAdd(&hist.depth_mom[depth_bin(cfg, ph)], dp);
     return 0;
+}
+
+// fly() then scatter() with the stream's own pairs: the generic kernel and the replay kernel.
+template <bool FAST, class Src, class Reemit>
+__device__ __forceinline__ int flight(const Cfg& cfg, Photon& ph, Src& src, Acc& acc, const Hist& hist,
+                                      Reemit&& reemit) {
+    if (ph.iter >= (uint32_t)cfg.max_events) return RT_FATE_GUARD;
+    double u_step, u_abs;
+    const int avail = src.pair(u_step, u_abs);
+    int n_used = 0;
+    const int fate = fly<FAST>(cfg, ph, u_step, u_abs, avail, Src::kBounded, acc, hist, reemit, n_used);
+    src.used(n_used);
+    if (fate != 0) return fate;
+    double u_phi, u_s;
+    const int avail2 = src.pair(u_phi, u_s);
+    return scatter<FAST>(cfg, ph, src, u_phi, u_s, avail2, acc, hist);
 }
 
 // Bookkeeping when a photon's history ends.

@@ -1,6 +1,7 @@
 // rt_kernels.hip -- gfx950 kernels of the photon random walk and their launchers.
 //
-//   walk_kernel<FAST>   persistent scatter kernel.  Every wave pulls work items
+//   walk_kernel /       persistent scatter kernels (generic / production configuration).
+//   walk_fast_kernel    Every wave pulls work items
 //                       (atmosphere, chunk of photon ids) from a global queue; inside a
 //                       chunk each lane carries one photon in registers and dead lanes are
 //                       refilled from the chunk with a ballot / prefix count.  A chunk is
@@ -30,16 +31,29 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
     return v;
 }
 
-// LDS layout per block: [waves][2*nd] doubles (depth momentum, depth energy), then [waves][nmu] u32.
+constexpr size_t kLogTableBytes = sizeof(LogTableEntry) * kLogTableEntries;
+
+// LDS layout per block: the logarithm table (2 KiB), then [waves][2*nd] doubles (depth momentum,
+// depth energy), then [waves][nmu] u32 (escape-cosine histogram).  The histograms are private
+// to a wave; the table is shared and read-only after stage_log_table().
 __device__ __forceinline__ Hist wave_hist(unsigned char* lds_raw, int wave, int nmu, int nd) {
-    double* depth_base = reinterpret_cast<double*>(lds_raw) + (size_t)wave * 2 * nd;
+    double* depth_base = reinterpret_cast<double*>(lds_raw + kLogTableBytes) + (size_t)wave * 2 * nd;
     uint32_t* mu_base =
-        reinterpret_cast<uint32_t*>(lds_raw + sizeof(double) * (size_t)kWavesPerBlock * 2 * nd) + (size_t)wave * nmu;
+        reinterpret_cast<uint32_t*>(lds_raw + kLogTableBytes + sizeof(double) * (size_t)kWavesPerBlock * 2 * nd) +
+        (size_t)wave * nmu;
     Hist h;
     h.mu = mu_base;
     h.depth_mom = nd ? depth_base : nullptr;
     h.depth_en = nd ? depth_base + nd : nullptr;
+    h.log_table = reinterpret_cast<const LogTableEntry*>(lds_raw);
     return h;
+}
+
+// Every thread of the block calls this once, before any divergence.
+__device__ __forceinline__ void stage_log_table(const Cfg& cfg, unsigned char* lds_raw) {
+    LogTableEntry* dst = reinterpret_cast<LogTableEntry*>(lds_raw);
+    for (int k = threadIdx.x; k < kLogTableEntries; k += blockDim.x) dst[k] = cfg.log_table[k];
+    __syncthreads();
 }
 
 __device__ __forceinline__ void clear_hist(const Hist& h, int lane, int nmu, int nd) {
@@ -66,7 +80,66 @@ __device__ __forceinline__ void flush_hist(const Hist& h, int lane, int nmu, int
     __builtin_amdgcn_wave_barrier();
 }
 
-template <bool FAST>
+// One unit of work for a wave: a chunk of consecutive photon ids of one atmosphere.
+struct WorkItem {
+    unsigned long long cursor, end;  // photon ids [cursor, end) before id_base is added
+    double tau;
+    uint32_t atm;
+    size_t slot;  // where this chunk's partial sums go
+};
+
+// Pops the next item of the global queue (wave-uniform).  Returns false when the queue is empty.
+__device__ __forceinline__ bool pop_item(const Sweep& sw, unsigned int* d_next, int lane, WorkItem& it) {
+    unsigned int q = 0;
+    if (lane == 0) q = atomicAdd(d_next, 1u);
+    q = __builtin_amdgcn_readfirstlane(q);
+    if (q >= sw.n_items) return false;
+    int lo = 0, hi = (int)sw.n_atm;  // sorted position with item_prefix[lo] <= q < item_prefix[lo+1]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (sw.item_prefix[mid] <= q)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    const AtmPlan plan = sw.plan[lo];
+    const unsigned int local = q - sw.item_prefix[lo];
+    const unsigned int j = local / plan.chunks_per_slab;  // ordinal among the slabs this rank owns
+    const unsigned int c = local - j * plan.chunks_per_slab;
+    const unsigned long long slab = (unsigned long long)sw.rank + (unsigned long long)j * sw.world;
+    const unsigned long long slab_lo = slab * plan.slab_len;
+    unsigned long long slab_hi = slab_lo + plan.slab_len;
+    slab_hi = slab_hi < plan.n_photons ? slab_hi : plan.n_photons;
+    it.cursor = slab_lo + (unsigned long long)c * plan.chunk;
+    const unsigned long long e = it.cursor + plan.chunk;
+    it.end = e < slab_hi ? e : slab_hi;
+    it.tau = plan.tau;
+    it.atm = plan.atm;
+    it.slot = (size_t)plan.slot_base + (size_t)j * plan.chunks_per_slab + c;
+    return true;
+}
+
+// Chunk epilogue: lanes reduced in a fixed butterfly, one partial per chunk; integer tallies
+// and histograms go to the global arrays with atomics (order-independent).
+__device__ __forceinline__ void store_chunk(const Acc& acc, const WorkItem& it, const Hist& hist, int lane, int nmu,
+                                            int nd, uint32_t n_atm, double* d_chunk_sums,
+                                            unsigned long long* d_counts, unsigned long long* d_mu_hist,
+                                            double* d_depth) {
+#pragma unroll
+    for (int k = 0; k < RT_NSUM; ++k) {
+        const double v = wave_sum(acc.s[k]);
+        if (lane == 0) d_chunk_sums[it.slot * RT_NSUM + k] = v;
+    }
+#pragma unroll
+    for (int k = 0; k < RT_NCNT; ++k) {
+        const uint32_t v = wave_sum_u32(acc.c[k]);
+        if (lane == 0 && v) atomicAdd(&d_counts[(size_t)it.atm * RT_NCNT + k], (unsigned long long)v);
+    }
+    flush_hist(hist, lane, nmu, nd, it.atm, n_atm, d_mu_hist, d_depth);
+}
+
+// Generic persistent kernel: every boundary / scattering law / loop order, depth bins, re-emission.
+// Per iteration: refill dead lanes, then one full flight (fly + scatter) per live lane.
 __global__ __launch_bounds__(kWalkBlock) void walk_kernel(const Cfg cfg, const Sweep sw,
                                                            unsigned int* __restrict__ d_next,
                                                            double* __restrict__ d_chunk_sums,
@@ -77,67 +150,43 @@ __global__ __launch_bounds__(kWalkBlock) void walk_kernel(const Cfg cfg, const S
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int nmu = cfg.n_mu_bins + 1;
-    const int nd = FAST ? 0 : cfg.n_depth_bins;
+    const int nd = cfg.n_depth_bins;
     const Hist hist = wave_hist(lds_raw, wave, nmu, nd);
+    stage_log_table(cfg, lds_raw);
     clear_hist(hist, lane, nmu, nd);
 
-    for (;;) {
-        // ---- pop one work item (wave-uniform) ----
-        unsigned int q = 0;
-        if (lane == 0) q = atomicAdd(d_next, 1u);
-        q = __builtin_amdgcn_readfirstlane(q);
-        if (q >= sw.n_items) break;
-        int lo = 0, hi = (int)sw.n_atm;  // sorted position with item_prefix[lo] <= q < item_prefix[lo+1]
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (sw.item_prefix[mid] <= q)
-                lo = mid;
-            else
-                hi = mid;
-        }
-        const AtmPlan plan = sw.plan[lo];
-        const unsigned int local = q - sw.item_prefix[lo];
-        const unsigned int j = local / plan.chunks_per_slab;  // ordinal among the slabs this rank owns
-        const unsigned int c = local - j * plan.chunks_per_slab;
-        const unsigned long long slab = (unsigned long long)sw.rank + (unsigned long long)j * sw.world;
-        const unsigned long long slab_lo = slab * plan.slab_len;
-        unsigned long long slab_hi = slab_lo + plan.slab_len;
-        slab_hi = slab_hi < plan.n_photons ? slab_hi : plan.n_photons;
-        unsigned long long cursor = slab_lo + (unsigned long long)c * plan.chunk;
-        unsigned long long end = cursor + plan.chunk;
-        end = end < slab_hi ? end : slab_hi;
-        const double tau = plan.tau;
-        const uint32_t atm = plan.atm;
-
+    WorkItem it;
+    while (pop_item(sw, d_next, lane, it)) {
+        const double tau = it.tau;
         Acc acc;
         acc.clear();
         Photon ph = {};
         PhiloxSrc src = {};
-        src.atm = atm;
+        src.atm = it.atm;
         src.k0 = cfg.k0;
         src.k1 = cfg.k1;
         bool alive = false;
 
         auto reemit = [&](Photon& p) {
             const double p0 = p.p0, e1 = p.e1, b = p.b;
-            const uint32_t it = p.iter;
+            const uint32_t n_it = p.iter;
             const int ns = p.n_scatter;
             emit_from_table(cfg, tau, src, p);
             p.p0 = p0;
             p.e1 = e1;
             p.b = b;
-            p.iter = it;
+            p.iter = n_it;
             p.n_scatter = ns;
         };
 
         for (;;) {
             // ---- refill dead lanes from the chunk (ballot + prefix count) ----
             const unsigned long long dead = __ballot(!alive);
-            if (dead != 0ull && cursor < end) {
+            if (dead != 0ull && it.cursor < it.end) {
                 const unsigned int my_off =
                     __builtin_amdgcn_mbcnt_hi((uint32_t)(dead >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dead, 0u));
-                const unsigned long long my_id = cursor + my_off;
-                if (!alive && my_id < end) {
+                const unsigned long long my_id = it.cursor + my_off;
+                if (!alive && my_id < it.end) {
                     const unsigned long long gid = my_id + cfg.id_base;
                     src.id_lo = (uint32_t)gid;
                     src.id_hi = (uint32_t)(gid >> 32);
@@ -147,32 +196,107 @@ __global__ __launch_bounds__(kWalkBlock) void walk_kernel(const Cfg cfg, const S
                     start_photon(ph, acc);
                     alive = true;
                 }
-                cursor += (unsigned long long)__popcll(dead);
+                it.cursor += (unsigned long long)__popcll(dead);
             }
             if (__ballot(alive) == 0ull) break;
             // ---- one flight for every live lane ----
             if (alive) {
-                const int fate = flight<FAST>(cfg, ph, src, acc, hist, reemit);
+                const int fate = flight<false>(cfg, ph, src, acc, hist, reemit);
                 if (fate != 0) {
                     retire(cfg, ph, fate, acc, hist);
                     alive = false;
                 }
             }
         }
+        store_chunk(acc, it, hist, lane, nmu, nd, sw.n_atm, d_chunk_sums, d_counts, d_mu_hist, d_depth);
+    }
+}
 
-        // ---- chunk epilogue: fixed-order lane reduction, one partial per chunk ----
-        const size_t slot = (size_t)plan.slot_base + (size_t)j * plan.chunks_per_slab + c;
-#pragma unroll
-        for (int k = 0; k < RT_NSUM; ++k) {
-            const double v = wave_sum(acc.s[k]);
-            if (lane == 0) d_chunk_sums[slot * RT_NSUM + k] = v;
+// Fast persistent kernel for the reference's production configuration: RT_ORDER_MC, reflecting
+// boundary, Henyey-Greenstein, no depth bins, abs_only off.  Same photon histories and tallies as
+// walk_kernel, but the loop is rotated so that the two lane populations that exist after a
+// flight -- lanes whose photon ended (they need a new photon) and lanes whose photon goes on to
+// scatter -- share ONE Philox call: each lane feeds its own counter (emission block of the new
+// photon id, or the scattering block of the current one) and the 128 output bits are then read
+// as the emission draws or as (azimuth, cosine).  The table record of the new photons is
+// requested before the scattering arithmetic runs, so the gather latency hides under it.
+__global__ __launch_bounds__(kWalkBlock) void walk_fast_kernel(const Cfg cfg, const Sweep sw,
+                                                                unsigned int* __restrict__ d_next,
+                                                                double* __restrict__ d_chunk_sums,
+                                                                unsigned long long* __restrict__ d_counts,
+                                                                unsigned long long* __restrict__ d_mu_hist,
+                                                                double* __restrict__ d_depth) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int nmu = cfg.n_mu_bins + 1;
+    const Hist hist = wave_hist(lds_raw, wave, nmu, 0);
+    stage_log_table(cfg, lds_raw);
+    clear_hist(hist, lane, nmu, 0);
+    auto no_reemit = [](Photon&) {};
+
+    WorkItem it;
+    while (pop_item(sw, d_next, lane, it)) {
+        const double tau = it.tau;
+        Acc acc;
+        acc.clear();
+        Photon ph = {};
+        PhiloxSrc src = {};
+        src.atm = it.atm;
+        src.k0 = cfg.k0;
+        src.k1 = cfg.k1;
+        bool alive = false;  // at the top of the loop a live lane is one that must scatter
+
+        for (;;) {
+            // ---- hand new photon ids to dead lanes (ballot + prefix count) ----
+            bool fresh = false;
+            const unsigned long long dead = __ballot(!alive);
+            if (dead != 0ull && it.cursor < it.end) {
+                const unsigned int my_off =
+                    __builtin_amdgcn_mbcnt_hi((uint32_t)(dead >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dead, 0u));
+                const unsigned long long my_id = it.cursor + my_off;
+                if (!alive && my_id < it.end) {
+                    const unsigned long long gid = my_id + cfg.id_base;
+                    src.id_lo = (uint32_t)gid;
+                    src.id_hi = (uint32_t)(gid >> 32);
+                    src.blk = 0u;
+                    fresh = true;
+                }
+                it.cursor += (unsigned long long)__popcll(dead);
+            }
+            const bool active = alive || fresh;
+            if (__ballot(active) == 0ull) break;
+            if (active) {
+                // ---- one Philox call: emission block for fresh lanes, scattering block otherwise ----
+                const uint32_t block = fresh ? kEmitBlock : src.blk;
+                const PhiloxOut o = philox4x32_10(src.id_lo, src.id_hi, block, src.atm, src.k0, src.k1);
+                const double ua = u53(o.w0, o.w1);
+                const double ub = u53(o.w2, o.w3);
+                const int idx = fresh ? sample_index(cfg, ua) : 0;
+                const TableRec rec = cfg.rec[idx];  // scattering lanes read record 0 (one line, broadcast)
+                if (!fresh) {
+                    ++src.blk;
+                    scatter<true>(cfg, ph, src, ua, ub, 2, acc, hist);
+                } else {
+                    set_constants(cfg, tau, rec, cfg.rand_mu ? ub : 1.0, ph);
+                    start_photon(ph, acc);
+                    alive = true;
+                }
+                // ---- flight: step, tests, absorption ----
+                int fate = RT_FATE_GUARD;
+                if (ph.iter < (uint32_t)cfg.max_events) {
+                    double u_step, u_abs;
+                    src.pair(u_step, u_abs);
+                    int n_used = 0;
+                    fate = fly<true>(cfg, ph, u_step, u_abs, 2, false, acc, hist, no_reemit, n_used);
+                }
+                if (fate != 0) {
+                    retire(cfg, ph, fate, acc, hist);
+                    alive = false;
+                }
+            }
         }
-#pragma unroll
-        for (int k = 0; k < RT_NCNT; ++k) {
-            const uint32_t v = wave_sum_u32(acc.c[k]);
-            if (lane == 0 && v) atomicAdd(&d_counts[(size_t)atm * RT_NCNT + k], (unsigned long long)v);
-        }
-        flush_hist(hist, lane, nmu, nd, atm, sw.n_atm, d_mu_hist, d_depth);
+        store_chunk(acc, it, hist, lane, nmu, 0, sw.n_atm, d_chunk_sums, d_counts, d_mu_hist, d_depth);
     }
 }
 
@@ -217,6 +341,7 @@ __global__ __launch_bounds__(kWalkBlock) void replay_kernel(const Cfg cfg, const
     const int nmu = cfg.n_mu_bins + 1;
     const int nd = cfg.n_depth_bins;
     const Hist hist = wave_hist(lds_raw, wave, nmu, nd);
+    stage_log_table(cfg, lds_raw);
     clear_hist(hist, lane, nmu, nd);
 
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -262,16 +387,36 @@ __global__ __launch_bounds__(kWalkBlock) void replay_kernel(const Cfg cfg, const
     flush_hist(hist, lane, nmu, nd, 0u, 1u, d_mu_hist, d_depth);
 }
 
+// The kernels' own ln() and cos(2 pi u) applied element-wise (test hook).
+__global__ void selftest_math_kernel(const LogTableEntry* __restrict__ table, long long n, const double* __restrict__ u,
+                                     double* __restrict__ out_log, double* __restrict__ out_cos) {
+    __shared__ LogTableEntry lds_table[kLogTableEntries];
+    for (int k = threadIdx.x; k < kLogTableEntries; k += blockDim.x) lds_table[k] = table[k];
+    __syncthreads();
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        out_log[i] = log_unit(u[i], lds_table);
+        out_cos[i] = cos_2pi(u[i]);
+    }
+}
+
 // ------------------------------- launchers -------------------------------
+hipError_t launch_selftest_math(const LogTableEntry* d_table, long long n, const double* d_u, double* d_log,
+                                double* d_cos, hipStream_t stream) {
+    selftest_math_kernel<<<(unsigned int)((n + 255) / 256), 256, 0, stream>>>(d_table, n, d_u, d_log, d_cos);
+    return hipGetLastError();
+}
+
 size_t walk_lds_bytes(const Cfg& cfg, bool fast) {
     const size_t nd = fast ? 0 : (size_t)cfg.n_depth_bins;
-    return sizeof(double) * kWavesPerBlock * 2 * nd + sizeof(uint32_t) * kWavesPerBlock * ((size_t)cfg.n_mu_bins + 1);
+    return kLogTableBytes + sizeof(double) * kWavesPerBlock * 2 * nd +
+           sizeof(uint32_t) * kWavesPerBlock * ((size_t)cfg.n_mu_bins + 1);
 }
 
 int walk_max_blocks_per_cu(bool fast, size_t lds_bytes) {
     int nb = 0;
-    hipError_t e = fast ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, walk_kernel<true>, kWalkBlock, lds_bytes)
-                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, walk_kernel<false>, kWalkBlock, lds_bytes);
+    hipError_t e = fast ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, walk_fast_kernel, kWalkBlock, lds_bytes)
+                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, walk_kernel, kWalkBlock, lds_bytes);
     if (e != hipSuccess || nb < 1) nb = 1;
     return nb;
 }
@@ -281,9 +426,9 @@ hipError_t launch_walk(const Cfg& cfg, const Sweep& sw, bool fast, int grid, hip
                        unsigned long long* d_mu_hist, double* d_depth) {
     const size_t lds = walk_lds_bytes(cfg, fast);
     if (fast)
-        walk_kernel<true><<<grid, kWalkBlock, lds, stream>>>(cfg, sw, d_next, d_chunk_sums, d_counts, d_mu_hist, d_depth);
+        walk_fast_kernel<<<grid, kWalkBlock, lds, stream>>>(cfg, sw, d_next, d_chunk_sums, d_counts, d_mu_hist, d_depth);
     else
-        walk_kernel<false><<<grid, kWalkBlock, lds, stream>>>(cfg, sw, d_next, d_chunk_sums, d_counts, d_mu_hist, d_depth);
+        walk_kernel<<<grid, kWalkBlock, lds, stream>>>(cfg, sw, d_next, d_chunk_sums, d_counts, d_mu_hist, d_depth);
     return hipGetLastError();
 }
 

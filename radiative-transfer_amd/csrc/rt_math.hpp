@@ -1,0 +1,79 @@
+// rt_math.hpp -- fp64 elementary functions shaped for the walk kernel (gfx950).
+//
+// The two transcendental calls of a loop iteration have very restricted arguments:
+//   step  = -ln(xi)            xi = k / 2^53 in [0, 1)          (TakeStep, MC code.py:496)
+//   cos(phi), phi = 2*pi*xi    xi in [0, 1)                     (RotateIntoLabFrame, MC code.py:615)
+// so neither needs the general-purpose library routines (argument reduction for huge angles,
+// subnormal handling, ...).  Both functions below are accurate to about 1e-16 ABSOLUTE
+// (<= 1.5 ulp of the result wherever the result is O(1)); the parity tests bound the effect.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rt {
+
+// ---------------------------------------------------------------------------
+// ln(x) for a normal x in (0, 1]; ln(0) = -inf.
+//   x = 2^e * m, m in [1,2);  j = top 7 fraction bits of m;  r = m * inv_c[j] - 1, |r| < 2^-8
+//   ln x = e ln2 + L[j] + log1p(r),   L[j] = -ln(inv_c[j]) for the ROUNDED inv_c[j]
+// The 128-entry table {inv_c, L} (2 KiB) is staged in LDS once per workgroup.
+// ---------------------------------------------------------------------------
+constexpr int kLogTableEntries = 128;
+
+struct LogTableEntry {
+    double inv_c;
+    double l;
+};
+
+__device__ __forceinline__ double log_unit(double x, const LogTableEntry* __restrict__ lds_table) {
+    const uint32_t hi = (uint32_t)__double2hiint(x);
+    const uint32_t lo = (uint32_t)__double2loint(x);
+    const int e = (int)(hi >> 20) - 1023;
+    const uint32_t j = (hi >> 13) & 127u;
+    const double m = __hiloint2double((int)((hi & 0x000FFFFFu) | 0x3FF00000u), (int)lo);
+    const LogTableEntry t = lds_table[j];
+    const double r = fma(m, t.inv_c, -1.0);
+    double p = fma(r, 1.0 / 7.0, -1.0 / 6.0);
+    p = fma(r, p, 1.0 / 5.0);
+    p = fma(r, p, -1.0 / 4.0);
+    p = fma(r, p, 1.0 / 3.0);
+    p = fma(r, p, -0.5);
+    const double r2 = r * r;
+    p = fma(r2, p, r);  // log1p(r)
+    const double ed = (double)e;
+    const double head = fma(ed, 6.93147180369123816490e-01, t.l);  // e * ln2_hi + L[j]
+    const double tail = fma(ed, 1.90821492927058770002e-10, p);    // e * ln2_lo + log1p(r)
+    const double res = head + tail;
+    return x == 0.0 ? -__builtin_inf() : res;
+}
+
+// ---------------------------------------------------------------------------
+// cos(2*pi*u) for u in [0, 1).  Quadrant reduction is exact in u:
+//   t = 4u, q = rint(t), x = (t - q) * pi/2 in [-pi/4, pi/4]; cos(2 pi u) = cos(x + q pi/2).
+// Kernel polynomials: the minimax sets of fdlibm's k_cos.c / k_sin.c.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double cos_2pi(double u) {
+    const double t = u * 4.0;
+    const double q = rint(t);
+    const double x = (t - q) * 1.57079632679489661923;
+    const int n = (int)q;
+    const double z = x * x;
+    double s = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    s = fma(z, s, 2.75573137070700676789e-06);
+    s = fma(z, s, -1.98412698298579493134e-04);
+    s = fma(z, s, 8.33333333332248946124e-03);
+    s = fma(z, s, -1.66666666666666324348e-01);
+    s = fma(x * z, s, x);  // sin x
+    double c = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    c = fma(z, c, -2.75573143513906633035e-07);
+    c = fma(z, c, 2.48015872894767294178e-05);
+    c = fma(z, c, -1.38888888888741095749e-03);
+    c = fma(z, c, 4.16666666666666019037e-02);
+    c = fma(z, c, -0.5);
+    c = fma(z, c, 1.0);  // cos x
+    const double v = (n & 1) ? s : c;
+    return ((n + 1) & 2) ? -v : v;  // q = 0: c, 1: -s, 2: -c, 3: s, 4: c
+}
+
+}  // namespace rt

@@ -167,6 +167,13 @@ class Engine:
                                         C.byref(res._c), trace.ctypes.data_as(C.POINTER(abi.RtPhotonTrace))))
         return res, trace
 
+    def selftest_math(self, u):
+        """The device's ln(u) and cos(2 pi u) for u in [0,1) (test hook)."""
+        u = np.ascontiguousarray(u, dtype=np.float64)
+        out_log, out_cos = np.empty_like(u), np.empty_like(u)
+        self._check(self._lib.rt_selftest_math(self._ctx, len(u), _dp(u), _dp(out_log), _dp(out_cos)))
+        return out_log, out_cos
+
     def kernel_time(self, reset=False):
         ms, n = C.c_double(), C.c_int64()
         self._check(self._lib.rt_kernel_time(self._ctx, C.byref(ms), C.byref(n), int(reset)))

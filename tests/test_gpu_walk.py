@@ -121,3 +121,23 @@ def test_errors(rt, engine):
         engine.run(rt.make_params(1.0, 100, scatter="draine"))
     with pytest.raises(rt.RtError):
         engine.run(rt.make_params(1.0, 100, world=3))
+
+
+def test_device_math_accuracy(engine):
+    """The kernels' own ln(u) and cos(2 pi u) against NumPy in extended precision."""
+    rng = np.random.default_rng(7)
+    u = np.concatenate([rng.random(200000), 2.0 ** -rng.integers(1, 53, 2000) * rng.random(2000),
+                        1 - 2.0 ** -rng.integers(1, 53, 2000), [2.0 ** -53, 0.25, 0.5, 0.75, 1 - 2.0 ** -53, 0.125]])
+    u = np.floor(u * 2.0 ** 53) / 2.0 ** 53
+    u = u[u > 0]
+    got_log, got_cos = engine.selftest_math(u)
+    ul = u.astype(np.longdouble)
+    want_log = np.log(ul)
+    err = np.abs(got_log.astype(np.longdouble) - want_log)
+    assert float(np.max(err / np.maximum(np.abs(want_log), 1.0))) < 4e-16  # absolute below |ln| = 1, relative above
+    want_cos = np.cos(2 * np.pi * ul)  # exact angle, not the rounded product 2*pi*u
+    assert float(np.max(np.abs(got_cos.astype(np.longdouble) - want_cos))) < 3e-16
+    # and against what the reference computes: np.cos(2*np.pi*u) with the product rounded to double
+    assert float(np.max(np.abs(got_cos - np.cos(2 * np.pi * u)))) < 1.2e-15
+    lz, _ = engine.selftest_math(np.array([0.0]))
+    assert np.isneginf(lz[0])
