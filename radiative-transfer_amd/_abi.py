@@ -64,7 +64,7 @@ def load_library(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    path = path or LIB_PATH
+    path = path or os.environ.get("RT_AMD_LIB") or LIB_PATH  # RT_AMD_LIB: A/B builds of the same ABI
     if not os.path.exists(path):
         raise OSError(f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                       "(hipcc --offload-arch=gfx950); there is no CPU fallback")
@@ -88,6 +88,5 @@ def load_library(path=None):
             getattr(lib, name).restype = C.c_int
     if lib.rt_abi_version() != RT_ABI_VERSION:
         raise OSError(f"{path}: ABI version {lib.rt_abi_version()} != {RT_ABI_VERSION}")
-    if path == LIB_PATH:
-        _lib = lib
+    _lib = lib
     return lib

@@ -14,7 +14,7 @@ def main(root):
     for path in sorted(glob.glob(os.path.join(root, "*", "*", "*counter_collection.csv"))):
         with open(path) as fh:
             for row in csv.DictReader(fh):
-                if "walk_kernel" not in row["Kernel_Name"]:
+                if "rt::walk_" not in row["Kernel_Name"]:
                     continue
                 name = row["Counter_Name"]
                 totals[name] = totals.get(name, 0.0) + float(row["Counter_Value"])
