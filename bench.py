@@ -56,6 +56,21 @@ def cpu_baseline(cfg, n_cpu, seconds_cap=30.0):
                        f"({events} events in {dt:.1f} s, oracle/numpy_walk.py, 1 process)")
 
 
+def measured_traffic(workload, per_gpu):
+    """HBM-side bytes per kernel launch from the committed PMC passes (profiles/*_traffic.json), if one
+    was taken for exactly this workload; rocprofv3 cannot be run from inside the benchmark."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json"))):
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        if d.get("workload") == workload and int(d.get("photons_per_atmosphere", -1)) == int(per_gpu):
+            best = d
+    return None if best is None else float(best["bytes_per_launch"])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -157,7 +172,8 @@ def main():
                        "parallelism": f"photon-id slabs over {world} GPU(s), 1 all-reduce of tallies per step"},
             "photon_histories_per_s": float(last[:, A.CNT_PHOTONS].sum()) * args.steps / dt,
             "roofline": {"bound": "valu_fp64", "achieved": achieved, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP64_VECTOR_PEAK_TFLOPS, "traffic": None,
+                         "frac": achieved / FP64_VECTOR_PEAK_TFLOPS,
+                         "traffic": measured_traffic(cfg["name"], per_gpu),
                          "kernel": "walk_kernel", "kernel_avg_ms": kernel_ms, "kernel_launches": launches,
                          "flop_per_event": FP64_OPS_PER_EVENT},
         }
