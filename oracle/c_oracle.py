@@ -98,6 +98,14 @@ def philox(ctr, key):
     return list(o)
 
 
+def sample_indices(pdf, u):
+    pdf = np.ascontiguousarray(pdf, dtype=np.float64)
+    u = np.ascontiguousarray(u, dtype=np.float64)
+    out = np.zeros(len(u), dtype=np.int32)
+    lib().ora_sample_indices(C.c_int(len(pdf)), _dp(pdf), C.c_int(len(u)), _dp(u), out.ctypes.data_as(C.POINTER(C.c_int32)))
+    return out
+
+
 def sample_index(pdf, u):
     pdf = np.ascontiguousarray(pdf, dtype=np.float64)
     f = lib().ora_sample_index

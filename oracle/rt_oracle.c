@@ -67,38 +67,74 @@ static void block_uniforms(uint64_t id, uint32_t block, uint32_t atm, uint64_t s
     *ub = u53(w[2], w[3]);
 }
 
-/* ---------------- emission law: exact inverse CDF ----------------
- * cdf[i] = sum_{j<=i} min(max(pdf[j],0),1) accumulated left to right in double.
- * A uniform u selects the first index i with cdf[i] > u * cdf[n-1].           */
-static void build_cdf(int n, const double* pdf, double* cdf) {
-    double acc = 0.0;
+/* ---------------- emission law: Walker/Vose alias table ----------------
+ * P(index i) is proportional to w_i = min(max(pdf_i, 0), 1)  (AcceptReject, MC code.py:239-268: a
+ * candidate is accepted when xi < PDF[i]).  The table construction order is part of the definition of
+ * the photon streams and is restated here independently of the product's host code:
+ *   q_i = (w_i * n) / total; two stacks, "small" (q < 1) and "large" (q >= 1), filled in ascending
+ *   index order; pop one of each: prob[s] = q_s, alias[s] = l, q_l = (q_l + q_s) - 1, push l back on
+ *   the stack its new q belongs to; whatever is left keeps itself with probability 1.
+ * A uniform u selects bucket floor(u*n) and, inside it, the bucket's own index if frac(u*n) < prob,
+ * else its alias.                                                                                  */
+typedef struct { double* prob; int32_t* alias; int n; } alias_t;
+
+static int build_alias(int n, const double* pdf, alias_t* t) {
+    double* q = (double*)malloc(sizeof(double) * (size_t)n);
+    int32_t* small = (int32_t*)malloc(sizeof(int32_t) * (size_t)n);
+    int32_t* large = (int32_t*)malloc(sizeof(int32_t) * (size_t)n);
+    t->prob = (double*)malloc(sizeof(double) * (size_t)n);
+    t->alias = (int32_t*)malloc(sizeof(int32_t) * (size_t)n);
+    t->n = n;
+    double total = 0.0;
     for (int i = 0; i < n; ++i) {
         double p = pdf ? pdf[i] : 1.0;
         if (!(p > 0.0)) p = 0.0;
         if (p > 1.0) p = 1.0;
-        acc += p;
-        cdf[i] = acc;
+        q[i] = p;
+        total += p;
     }
+    int ns = 0, nl = 0;
+    for (int i = 0; i < n; ++i) {
+        q[i] = (q[i] * (double)n) / total;
+        if (q[i] < 1.0) small[ns++] = i; else large[nl++] = i;
+    }
+    while (ns > 0 && nl > 0) {
+        int32_t s = small[--ns], l = large[--nl];
+        t->prob[s] = q[s];
+        t->alias[s] = l;
+        q[l] = (q[l] + q[s]) - 1.0;
+        if (q[l] < 1.0) small[ns++] = l; else large[nl++] = l;
+    }
+    while (nl > 0) { int32_t i = large[--nl]; t->prob[i] = 1.0; t->alias[i] = i; }
+    while (ns > 0) { int32_t i = small[--ns]; t->prob[i] = 1.0; t->alias[i] = i; }
+    free(q); free(small); free(large);
+    return total > 0.0;
 }
 
-static int sample_index(int n, const double* cdf, double u) {
-    double t = u * cdf[n - 1];
-    int lo = 0, hi = n - 1; /* first i in [lo,hi] with cdf[i] > t; hi is the fallback */
-    while (lo < hi) {
-        int mid = lo + (hi - lo) / 2;
-        if (cdf[mid] > t) hi = mid; else lo = mid + 1;
-    }
-    /* if rounding pushed t up to the total, step back to the last entry with weight */
-    while (lo > 0 && !(cdf[lo] > cdf[lo - 1])) --lo;
-    return lo;
+static void free_alias(alias_t* t) { free(t->prob); free(t->alias); }
+
+static int sample_index(const alias_t* t, double u) {
+    double x = u * (double)t->n;
+    int i = (int)x;
+    if (i >= t->n) i = t->n - 1;
+    double frac = x - (double)i;
+    return frac < t->prob[i] ? i : t->alias[i];
 }
 
 int ora_sample_index(int n, const double* pdf, double u) {
-    double* cdf = (double*)malloc(sizeof(double) * (size_t)n);
-    build_cdf(n, pdf, cdf);
-    int i = sample_index(n, cdf, u);
-    free(cdf);
+    alias_t t;
+    build_alias(n, pdf, &t);
+    int i = sample_index(&t, u);
+    free_alias(&t);
     return i;
+}
+
+/* indices for many uniforms at once (tests of the emission law) */
+void ora_sample_indices(int n, const double* pdf, int m, const double* u, int32_t* out) {
+    alias_t t;
+    build_alias(n, pdf, &t);
+    for (int k = 0; k < m; ++k) out[k] = sample_index(&t, u[k]);
+    free_alias(&t);
 }
 
 /* ---------------- one photon ---------------- */
@@ -139,7 +175,7 @@ static int draw(stream_t* s, double* u) {
 typedef struct {
     int n_wl;
     const double *wl, *g, *albedo, *scale;
-    double* cdf;
+    alias_t alias;
     int mono_index; /* >= 0: monochromatic */
 } tables_t;
 
@@ -154,7 +190,7 @@ static void emit_philox(const rt_params* p, const tables_t* t, stream_t* s, cons
     double ua, ub;
     block_uniforms(s->id, EMIT_BLOCK + s->n_emit, s->atm, s->seed, &ua, &ub);
     s->n_emit++;
-    int i = t->mono_index >= 0 ? t->mono_index : sample_index(t->n_wl, t->cdf, ua);
+    int i = t->mono_index >= 0 ? t->mono_index : sample_index(&t->alias, ua);
     c->lam = t->wl[i];
     c->g = t->g[i];
     c->albedo = t->albedo[i];
@@ -354,14 +390,14 @@ int ora_replay(const rt_params* p, int64_t n, int32_t max_draws, const double* x
  * filled for atmosphere 0 only. */
 int ora_run(const rt_params* p, int32_t n_wl, const double* wl, const double* g, const double* albedo,
             const double* scale, const double* pdf, rt_tallies* out, rt_photon_trace* trace) {
-    tables_t t = {n_wl, wl, g, albedo, scale, NULL, -1};
-    t.cdf = (double*)malloc(sizeof(double) * (size_t)n_wl);
-    build_cdf(n_wl, pdf, t.cdf);
+    tables_t t;
+    t.n_wl = n_wl; t.wl = wl; t.g = g; t.albedo = albedo; t.scale = scale; t.mono_index = -1;
+    if (!build_alias(n_wl, pdf, &t.alias)) { free_alias(&t.alias); return RT_ERR_INVALID; }
     if (p->monochromatic_wl != 0) {
         double want = round(p->monochromatic_wl * 1e4) / 1e4;
         for (int i = 0; i < n_wl; ++i)
             if (wl[i] == want || wl[i] == p->monochromatic_wl) { t.mono_index = i; break; }
-        if (t.mono_index < 0) { free(t.cdf); return RT_ERR_INVALID; }
+        if (t.mono_index < 0) { free_alias(&t.alias); return RT_ERR_INVALID; }
     }
     const int n_slabs = p->n_slabs > 0 ? p->n_slabs : 8;
     const int world = p->world > 0 ? p->world : 1;
@@ -407,6 +443,6 @@ int ora_run(const rt_params* p, int32_t n_wl, const double* wl, const double* g,
         if (de) memcpy(de, de_l, sizeof(double) * (size_t)nd);
         free(dm_l); free(de_l);
     }
-    free(t.cdf);
+    free_alias(&t.alias);
     return 0;
 }

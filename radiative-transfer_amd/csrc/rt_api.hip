@@ -66,12 +66,10 @@ struct rt_ctx {
     hipDeviceProp_t prop;
     hipStream_t stream = nullptr;
     // tables
-    int32_t n_wl = 0, guide_k = 0;
-    double total = 0.0;
+    int32_t n_wl = 0;
     std::vector<double> wl;
     DevBuf<rt::TableRec> d_rec;
-    DevBuf<double> d_cdf;
-    DevBuf<int32_t> d_guide;
+    DevBuf<rt::AliasEntry> d_alias;
     DevBuf<rt::LogTableEntry> d_log_table;
     // sweep workspace
     DevBuf<rt::AtmPlan> d_plan;
@@ -126,12 +124,9 @@ rt::Cfg make_cfg(const rt_ctx* ctx, const rt_params* p) {
     c.k1 = (uint32_t)(p->seed >> 32);
     c.id_base = p->photon_id_base;
     c.rec = ctx->d_rec.p;
-    c.cdf = ctx->d_cdf.p;
-    c.guide = ctx->d_guide.p;
+    c.alias = ctx->d_alias.p;
     c.n_wl = ctx->n_wl;
-    c.guide_k = ctx->guide_k;
     c.mono_index = -1;
-    c.total = ctx->total;
     c.log_table = ctx->d_log_table.p;
     return c;
 }
@@ -236,8 +231,7 @@ int rt_destroy(rt_ctx* ctx) {
         (void)hipEventDestroy(e.b);
     }
     ctx->d_rec.release();
-    ctx->d_cdf.release();
-    ctx->d_guide.release();
+    ctx->d_alias.release();
     ctx->d_log_table.release();
     ctx->d_plan.release();
     ctx->d_prefix.release();
@@ -269,40 +263,46 @@ int rt_set_tables(rt_ctx* ctx, int32_t n_wl, const double* wl, const double* g, 
     if (n_wl > (1 << 24)) return fail(RT_ERR_LIMIT, "n_wl %d exceeds 2^24", n_wl);
     RT_HIP(hipSetDevice(ctx->device));
     std::vector<rt::TableRec> rec((size_t)n_wl);
-    std::vector<double> cdf((size_t)n_wl);
-    double acc = 0.0;
-    int last = -1;
+    std::vector<double> w((size_t)n_wl);
+    double total = 0.0;
     for (int i = 0; i < n_wl; ++i) {
-        rec[i] = {wl[i], 1.0 / wl[i], g[i], albedo[i], scale[i], 1.0 / (2.0 * g[i]), 1.0 + g[i] * g[i], 1.0 - g[i] * g[i]};
+        rec[i] = {wl[i], g[i], albedo[i], scale[i]};
         double p = pdf ? pdf[i] : 1.0;
         if (!(p > 0.0)) p = 0.0;  // also maps NaN to 0
         if (p > 1.0) p = 1.0;     // AcceptReject accepts with probability min(PDF, 1)
-        if (p > 0.0) last = i;
-        acc += p;
-        cdf[i] = acc;
+        w[i] = p;
+        total += p;
     }
-    if (last < 0) return fail(RT_ERR_INVALID, "emission law has no positive weight");
-    // guide[k] = first index i <= last with cdf[i] > (k/K)*total, or `last` if there is none
-    int K = 64;
-    while (K < n_wl) K <<= 1;
-    std::vector<int32_t> guide((size_t)K + 1);
-    int i = 0;
-    for (int k = 0; k <= K; ++k) {
-        const double t = ((double)k / (double)K) * acc;
-        while (i < last && !(cdf[i] > t)) ++i;
-        guide[k] = i;
+    if (!(total > 0.0)) return fail(RT_ERR_INVALID, "emission law has no positive weight");
+    // Alias table (Vose).  The construction order is part of the definition of the photon streams:
+    // q_i = (w_i * n) / total; wavelengths with q < 1 ("small") and q >= 1 ("large") are kept on two
+    // stacks filled in ascending index order; pop one of each, the small one keeps q and points to the
+    // large one, whose excess (q_l + q_s) - 1 decides on which stack it goes back.
+    std::vector<rt::AliasEntry> alias((size_t)n_wl);
+    std::vector<double> q((size_t)n_wl);
+    std::vector<int32_t> small, large;
+    small.reserve((size_t)n_wl);
+    large.reserve((size_t)n_wl);
+    for (int i = 0; i < n_wl; ++i) {
+        q[i] = (w[i] * (double)n_wl) / total;
+        (q[i] < 1.0 ? small : large).push_back(i);
     }
-    guide[K] = last;
+    while (!small.empty() && !large.empty()) {
+        const int32_t s = small.back(), l = large.back();
+        small.pop_back();
+        large.pop_back();
+        alias[s] = {q[s], l, 0};
+        q[l] = (q[l] + q[s]) - 1.0;
+        (q[l] < 1.0 ? small : large).push_back(l);
+    }
+    for (int32_t i : large) alias[i] = {1.0, i, 0};
+    for (int32_t i : small) alias[i] = {1.0, i, 0};  // only reachable through rounding; q is 1 to within an ulp
     RT_HIP(ctx->d_rec.reserve((size_t)n_wl));
-    RT_HIP(ctx->d_cdf.reserve((size_t)n_wl));
-    RT_HIP(ctx->d_guide.reserve((size_t)K + 1));
+    RT_HIP(ctx->d_alias.reserve((size_t)n_wl));
     RT_HIP(hipStreamSynchronize(ctx->stream));
     RT_HIP(hipMemcpy(ctx->d_rec.p, rec.data(), sizeof(rt::TableRec) * (size_t)n_wl, hipMemcpyHostToDevice));
-    RT_HIP(hipMemcpy(ctx->d_cdf.p, cdf.data(), sizeof(double) * (size_t)n_wl, hipMemcpyHostToDevice));
-    RT_HIP(hipMemcpy(ctx->d_guide.p, guide.data(), sizeof(int32_t) * ((size_t)K + 1), hipMemcpyHostToDevice));
+    RT_HIP(hipMemcpy(ctx->d_alias.p, alias.data(), sizeof(rt::AliasEntry) * (size_t)n_wl, hipMemcpyHostToDevice));
     ctx->n_wl = n_wl;
-    ctx->guide_k = K;
-    ctx->total = acc;
     ctx->wl.assign(wl, wl + n_wl);
     return RT_OK;
 }

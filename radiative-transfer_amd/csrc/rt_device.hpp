@@ -62,12 +62,20 @@ __device__ __forceinline__ double u53(uint32_t a, uint32_t b) {
 // ---------------------------------------------------------------------------
 // Run configuration (wave-uniform; passed by value as a kernel argument).
 // ---------------------------------------------------------------------------
-struct TableRec {  // one wavelength: what CreatePhotons copies into a photon row, plus the
-                   // per-photon constants of GetZMomentum and HGScatter, precomputed on the host
-                   // with the reference's own expressions (1/lambda, 1/(2*g), 1+g**2, 1-g**2)
-    double lam, inv_lam, g, albedo, scale, inv2g, opg2, omg2;
+struct TableRec {  // one wavelength: what CreatePhotons copies into a photon row (MC code.py:403-408)
+    double lam, g, albedo, scale;
 };
-static_assert(sizeof(TableRec) == 64, "one table record per 64-byte line");
+static_assert(sizeof(TableRec) == 32, "two 16-byte loads per record");
+
+// Walker/Vose alias table of the emission law: bucket i (one per wavelength) keeps wavelength i with
+// probability `prob` and hands the rest of its 1/n share to wavelength `alias`.  One 16-byte load and no
+// data-dependent loop per emission, whatever the shape of the law.
+struct AliasEntry {
+    double prob;
+    int32_t alias;
+    int32_t pad_;
+};
+static_assert(sizeof(AliasEntry) == 16, "one 16-byte load per entry");
 
 struct Cfg {
     int32_t boundary, scatter, order, rand_mu, abs_only;
@@ -77,10 +85,8 @@ struct Cfg {
     uint64_t id_base;
     // emission tables
     const TableRec* rec;
-    const double* cdf;     // unnormalised cumulative weights, n_wl entries
-    const int32_t* guide;  // guide[k] = first index whose cdf exceeds (k/K)*total, K+1 entries
-    int32_t n_wl, guide_k, mono_index;
-    double total;
+    const AliasEntry* alias;  // n_wl entries
+    int32_t n_wl, mono_index;
     const LogTableEntry* log_table;  // kLogTableEntries entries in global memory (copied to LDS per workgroup)
 };
 
@@ -156,22 +162,22 @@ struct ReplaySrc {
 // Emission: wavelength index from the tabulated law, then the photon constants.
 // P(index i) is proportional to min(max(pdf_i,0),1)  (AcceptReject, MC code.py:239-268).
 // ---------------------------------------------------------------------------
+// u in [0,1) -> wavelength index with P(i) proportional to the table weights:
+// x = u*n, bucket = floor(x), keep the bucket's own wavelength if frac(x) < prob, else its alias.
 __device__ __forceinline__ int sample_index(const Cfg& cfg, double u) {
     if (cfg.mono_index >= 0) return cfg.mono_index;
-    const double t = u * cfg.total;
-    const int k = (int)(u * (double)cfg.guide_k);
-    int lo = cfg.guide[k];
-    int hi = cfg.guide[k + 1];
-    while (lo < hi) {  // first i in [lo, hi] with cdf[i] > t (hi is the fallback)
-        const int mid = lo + ((hi - lo) >> 1);
-        if (cfg.cdf[mid] > t)
-            hi = mid;
-        else
-            lo = mid + 1;
-    }
-    return lo;
+    const double x = u * (double)cfg.n_wl;
+    int i = (int)x;
+    i = i < cfg.n_wl ? i : cfg.n_wl - 1;  // u*n can round up to n for u = 1 - 2^-53
+    const double frac = x - (double)i;
+    const uint4 raw = *reinterpret_cast<const uint4*>(&cfg.alias[i]);  // one 16-byte load
+    const double prob = __hiloint2double((int)raw.y, (int)raw.x);
+    return frac < prob ? i : (int)raw.z;
 }
 
+// Per-photon constants from the photon's row values.  1/lambda, 1/(2*g), 1+g**2 and 1-g**2 are the
+// sub-expressions GetZMomentum and HGScatter evaluate for every photon on every call
+// (MC code.py:367, :439); they depend on the photon only, so they are formed once here (IEEE division).
 __device__ __forceinline__ void set_constants(const Cfg& cfg, double tau, double lam, double g, double albedo,
                                               double scale, double mu0, Photon& ph) {
     const double w = cfg.order == RT_ORDER_GRAY ? lam : 1.0 / lam;
@@ -186,23 +192,20 @@ __device__ __forceinline__ void set_constants(const Cfg& cfg, double tau, double
     ph.mu = mu0;
 }
 
+__device__ __forceinline__ TableRec load_record(const Cfg& cfg, int i) {
+    const double2* p = reinterpret_cast<const double2*>(&cfg.rec[i]);  // two 16-byte loads
+    const double2 a = p[0], b = p[1];
+    return {a.x, a.y, b.x, b.y};
+}
+
 __device__ __forceinline__ void set_constants(const Cfg& cfg, double tau, const TableRec& r, double mu0, Photon& ph) {
-    ph.wh = (cfg.order == RT_ORDER_GRAY ? r.lam : r.inv_lam) * cfg.h;
-    ph.g = r.g;
-    ph.albedo = r.albedo;
-    ph.zmax = tau * r.scale;
-    ph.inv2g = r.inv2g;
-    ph.opg2 = r.opg2;
-    ph.omg2 = r.omg2;
-    ph.z = 0.0;
-    ph.mu = mu0;
+    set_constants(cfg, tau, r.lam, r.g, r.albedo, r.scale, mu0, ph);
 }
 
 __device__ __forceinline__ void emit_from_table(const Cfg& cfg, double tau, PhiloxSrc& src, Photon& ph) {
     double ua, ub;
     src.emit_pair(ua, ub);
-    const int i = sample_index(cfg, ua);
-    const TableRec r = cfg.rec[i];
+    const TableRec r = load_record(cfg, sample_index(cfg, ua));
     set_constants(cfg, tau, r, cfg.rand_mu ? ub : 1.0, ph);
 }
 

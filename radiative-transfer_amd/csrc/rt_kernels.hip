@@ -273,7 +273,7 @@ __global__ __launch_bounds__(kWalkBlock) void walk_fast_kernel(const Cfg cfg, co
                 const double ua = u53(o.w0, o.w1);
                 const double ub = u53(o.w2, o.w3);
                 const int idx = fresh ? sample_index(cfg, ua) : 0;
-                const TableRec rec = cfg.rec[idx];  // scattering lanes read record 0 (one line, broadcast)
+                const TableRec rec = load_record(cfg, idx);  // scattering lanes read record 0 (one line, broadcast)
                 if (!fresh) {
                     ++src.blk;
                     scatter<true>(cfg, ph, src, ua, ub, 2, acc, hist);

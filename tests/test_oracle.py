@@ -121,14 +121,22 @@ def test_c_oracle_production_statistics(c_oracle):
 
 
 def test_emission_index_law(c_oracle):
-    pdf = np.array([0.0, 0.2, 0.0, 0.0, 0.5, 2.0, 0.0])  # 2.0 is clipped to 1 (acceptance probability)
-    w = np.array([0, .2, 0, 0, .5, 1., 0]) / 1.7
-    us = (np.arange(20000) + 0.5) / 20000
-    idx = np.array([c_oracle.sample_index(pdf, float(u)) for u in us])
-    freq = np.bincount(idx, minlength=7) / len(us)
-    np.testing.assert_allclose(freq, w, atol=2e-4)
-    assert c_oracle.sample_index(pdf, 0.0) == 1
-    assert c_oracle.sample_index(pdf, np.nextafter(1.0, 0.0)) == 5
+    """P(index) proportional to min(max(pdf, 0), 1): the law of AcceptReject (MC code.py:239-268)."""
+    pdf = np.array([0.0, 0.2, 0.0, np.nan, 0.5, 2.0, -1.0, 1e-9])  # 2.0 is clipped to 1 (acceptance probability)
+    w = np.array([0, .2, 0, 0, .5, 1., 0, 1e-9])
+    w = w / w.sum()
+    us = (np.arange(400000) + 0.5) / 400000
+    idx = c_oracle.sample_indices(pdf, us)
+    freq = np.bincount(idx, minlength=len(pdf)) / len(us)
+    np.testing.assert_allclose(freq, w, atol=1e-5)
+    assert freq[0] == freq[2] == freq[3] == freq[6] == 0          # zero weight is never emitted
+    assert c_oracle.sample_index(pdf, np.nextafter(1.0, 0.0)) in (1, 4, 5, 7)
+    # a broad, very uneven law (4 decades) is reproduced to the resolution of the stratified sample
+    rng = np.random.default_rng(3)
+    pdf = 10.0 ** rng.uniform(-9, -5, 5000)
+    idx = c_oracle.sample_indices(pdf, us)
+    freq = np.bincount(idx, minlength=5000) / len(us)
+    assert np.abs(freq - pdf / pdf.sum()).max() < 3.0 / len(us)
 
 
 def test_known_answer_two_stream(c_oracle):
