@@ -266,7 +266,7 @@ int rt_set_tables(rt_ctx* ctx, int32_t n_wl, const double* wl, const double* g, 
     std::vector<double> w((size_t)n_wl);
     double total = 0.0;
     for (int i = 0; i < n_wl; ++i) {
-        rec[i] = {wl[i], g[i], albedo[i], scale[i]};
+        rec[i] = {wl[i], g[i], albedo[i], scale[i], 1.0 / wl[i], 1.0 / (2.0 * g[i])};
         double p = pdf ? pdf[i] : 1.0;
         if (!(p > 0.0)) p = 0.0;  // also maps NaN to 0
         if (p > 1.0) p = 1.0;     // AcceptReject accepts with probability min(PDF, 1)

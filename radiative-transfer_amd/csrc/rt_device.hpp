@@ -38,8 +38,11 @@ struct PhiloxOut {
 
 __device__ __forceinline__ PhiloxOut philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
                                                    uint32_t k1) {
+#ifndef RT_PHILOX_ROUNDS
+#define RT_PHILOX_ROUNDS 10  // timing experiments only; every result check assumes 10
+#endif
 #pragma unroll
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < RT_PHILOX_ROUNDS; ++r) {
         const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
         const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
         const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
@@ -62,10 +65,12 @@ __device__ __forceinline__ double u53(uint32_t a, uint32_t b) {
 // ---------------------------------------------------------------------------
 // Run configuration (wave-uniform; passed by value as a kernel argument).
 // ---------------------------------------------------------------------------
-struct TableRec {  // one wavelength: what CreatePhotons copies into a photon row (MC code.py:403-408)
-    double lam, g, albedo, scale;
+struct TableRec {  // one wavelength: what CreatePhotons copies into a photon row (MC code.py:403-408), with
+                   // the two per-photon quotients GetZMomentum and HGScatter form on every call, 1/lambda and
+                   // 1/(2*g) (MC code.py:367, :439), taken once on the host (IEEE division, as NumPy's)
+    double lam, g, albedo, scale, inv_lam, inv2g;
 };
-static_assert(sizeof(TableRec) == 32, "two 16-byte loads per record");
+static_assert(sizeof(TableRec) == 48, "three 16-byte loads per record");
 
 // Walker/Vose alias table of the emission law: bucket i (one per wavelength) keeps wavelength i with
 // probability `prob` and hands the rest of its 1/n share to wavelength `alias`.  One 16-byte load and no
@@ -170,9 +175,17 @@ __device__ __forceinline__ int sample_index(const Cfg& cfg, double u) {
     int i = (int)x;
     i = i < cfg.n_wl ? i : cfg.n_wl - 1;  // u*n can round up to n for u = 1 - 2^-53
     const double frac = x - (double)i;
+#ifdef RT_ABLATE_ALIAS
+    return frac < 0.5 ? i : (i ^ 1);
+#elif defined(RT_ABLATE_ALIAS_NODEP)
+    const uint4 raw = *reinterpret_cast<const uint4*>(&cfg.alias[i]);  // loaded but not waited for here
+    asm volatile("" ::"v"(raw.x), "v"(raw.z));
+    return frac < 0.5 ? i : (i ^ 1);
+#else
     const uint4 raw = *reinterpret_cast<const uint4*>(&cfg.alias[i]);  // one 16-byte load
     const double prob = __hiloint2double((int)raw.y, (int)raw.x);
     return frac < prob ? i : (int)raw.z;
+#endif
 }
 
 // Per-photon constants from the photon's row values.  1/lambda, 1/(2*g), 1+g**2 and 1-g**2 are the
@@ -193,13 +206,21 @@ __device__ __forceinline__ void set_constants(const Cfg& cfg, double tau, double
 }
 
 __device__ __forceinline__ TableRec load_record(const Cfg& cfg, int i) {
-    const double2* p = reinterpret_cast<const double2*>(&cfg.rec[i]);  // two 16-byte loads
-    const double2 a = p[0], b = p[1];
-    return {a.x, a.y, b.x, b.y};
+    const double2* p = reinterpret_cast<const double2*>(&cfg.rec[i]);  // three 16-byte loads
+    const double2 a = p[0], b = p[1], c = p[2];
+    return {a.x, a.y, b.x, b.y, c.x, c.y};
 }
 
 __device__ __forceinline__ void set_constants(const Cfg& cfg, double tau, const TableRec& r, double mu0, Photon& ph) {
-    set_constants(cfg, tau, r.lam, r.g, r.albedo, r.scale, mu0, ph);
+    ph.wh = (cfg.order == RT_ORDER_GRAY ? r.lam : r.inv_lam) * cfg.h;
+    ph.g = r.g;
+    ph.albedo = r.albedo;
+    ph.zmax = tau * r.scale;
+    ph.inv2g = r.inv2g;
+    ph.opg2 = 1.0 + r.g * r.g;
+    ph.omg2 = 1.0 - r.g * r.g;
+    ph.z = 0.0;
+    ph.mu = mu0;
 }
 
 __device__ __forceinline__ void emit_from_table(const Cfg& cfg, double tau, PhiloxSrc& src, Photon& ph) {
