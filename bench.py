@@ -81,6 +81,8 @@ def main():
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--cpu-photons", type=int, default=1000000)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="gloo stages the tallies through host memory; for rehearsing N > 1 on a box with fewer GPUs than ranks")
     args = ap.parse_args()
 
     import torch
@@ -95,10 +97,17 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU path")
-    torch.cuda.set_device(local_rank)
+    n_dev = torch.cuda.device_count()
+    if args.backend == "nccl" and local_rank >= n_dev:
+        raise SystemExit(f"rank {local_rank} has no GPU ({n_dev} visible); RCCL needs one GPU per rank")
+    local_dev = local_rank % n_dev  # only ever differs from local_rank in a gloo rehearsal
+    torch.cuda.set_device(local_dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_dev))
+        else:
+            dist.init_process_group("gloo")
 
     rt = importlib.import_module("radiative-transfer_amd")
     workloads = importlib.import_module("radiative-transfer_amd.workloads")
@@ -110,9 +119,9 @@ def main():
     tau = cfg["tau_list"]
     n_atm = len(tau)
 
-    eng = rt.Engine(local_rank)
+    eng = rt.Engine(local_dev)
     eng.set_tables(cfg["wl"], cfg["g"], cfg["albedo"], cfg["scale"], cfg["pdf"])
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", local_dev)
     slab = torch.zeros(n_atm * n_slabs * A.NSUM, dtype=torch.float64, device=dev)
     counts = torch.zeros(n_atm * A.NCNT, dtype=torch.int64, device=dev)
     hist = torch.zeros(n_atm * 11, dtype=torch.int64, device=dev)
@@ -125,9 +134,15 @@ def main():
         eng.run_device(prm, slab.data_ptr(), counts.data_ptr(), hist.data_ptr(), None, stream)
         if world > 1:
             # every slab entry is non-zero on exactly one rank, so the sum is exact and order-free
-            dist.all_reduce(slab)
-            dist.all_reduce(counts)
-            dist.all_reduce(hist)
+            if args.backend == "nccl":
+                dist.all_reduce(slab)
+                dist.all_reduce(counts)
+                dist.all_reduce(hist)
+            else:
+                for t in (slab, counts, hist):
+                    h = t.cpu()
+                    dist.all_reduce(h)
+                    t.copy_(h)
         # scatter events of this step (whole job after the all-reduce), kept on the device
         return counts.view(n_atm, A.NCNT)[:, A.CNT_SCATTER].sum()
 
@@ -148,7 +163,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     events = int(ev_dev.item())          # after the all-reduce this is the whole job's count
@@ -165,8 +180,8 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"{cfg['name']}: {n_atm} atmospheres tau=logspace(-3,2,100) x {per_gpu:.3g} photons "
-                                   f"per atmosphere per GPU, Sil/Gra/SiC MRN mix, Planck(3e4 K) emission, reflect + hg",
+            "config": {"workload": f"{cfg['name']}: {n_atm} atmospheres tau={tau[0]:.3g}..{tau[-1]:.3g} (log-spaced) x "
+                                   f"{per_gpu:.3g} photons per atmosphere per GPU, {cfg['describe']}",
                        "photons_per_atmosphere_global": total_photons, "photon_histories_per_step": int(last[:, A.CNT_PHOTONS].sum()),
                        "flights_per_step": int(last[:, A.CNT_FLIGHTS].sum()), "events_per_step": events_last,
                        "parallelism": f"photon-id slabs over {world} GPU(s), 1 all-reduce of tallies per step"},

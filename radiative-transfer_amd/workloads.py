@@ -17,7 +17,7 @@ def _finish(name, grain, tau_list, n_photons, **extra):
     wl = np.asarray(grain["WL"], dtype=float)
     sed = tables.planck_sed(wl)
     pdf, _ = tables.photon_pdf(wl, sed)
-    out = dict(name=name, wl=wl, g=np.asarray(grain["g"], dtype=float), albedo=np.asarray(grain["Albedo"], dtype=float),
+    out = dict(name=name, describe=extra.pop("describe", name), wl=wl, g=np.asarray(grain["g"], dtype=float), albedo=np.asarray(grain["Albedo"], dtype=float),
                scale=np.asarray(grain["Scale"], dtype=float), pdf=pdf, tau_list=np.asarray(tau_list, dtype=float),
                n_photons=int(n_photons), order="mc", boundary="reflect", scatter="hg", h=tables.H_PLANCK,
                monochromatic=0.0)
@@ -29,28 +29,32 @@ def gray_1e5():
     """Config 1 (plumbing): gray dust, albedo 0.9 (Numpy_random_walk.py:13), g = 0.5, 10 atmospheres."""
     return dict(name="gray_1e5", wl=np.array([1.0]), g=np.array([0.5]), albedo=np.array([0.9]), scale=np.array([1.0]),
                 pdf=None, tau_list=TAU_LIST_GRAY, n_photons=100000, order="gray", boundary="reflect", scatter="hg",
-                h=1.0, monochromatic=1.0, h_g=None)
+                h=1.0, monochromatic=1.0, h_g=None,
+                describe="gray dust albedo 0.9 g 0.5, gray-script loop order, reflect + hg")
 
 
 def sil_single_1e6(wl_list=None):
     """Config 2: one silicate grain size (0.1 um), wavelength-dependent albedo / g / Scale, 1e6 photons per
     atmosphere, 100 atmospheres; shell radius h_g = 5 pc only converts tau to a column density afterwards."""
     grain = tables.single_grain_data("Sil", 0.1, wl_list)
-    return _finish("sil_single_1e6", grain, TAU_LIST_MC, 1000000, h_g=5)
+    return _finish("sil_single_1e6", grain, TAU_LIST_MC, 1000000, h_g=5,
+                   describe="one silicate grain size (0.1 um), Planck(3e4 K) emission, reflect + hg")
 
 
 def mix_2e7(wl_list=None, n_photons=20000000):
     """Config 3 (headline): Sil/Gra/SiC mix [0.5, 0.45, 0.05], MRN sizes 0.001-1 um, 2e7 photons per
     atmosphere, 100 atmospheres, h_g = 10 pc."""
     grain = tables.grain_data("mix", 0.001, 1, wl_list)
-    return _finish("mix_2e7", grain, TAU_LIST_MC, n_photons, h_g=10)
+    return _finish("mix_2e7", grain, TAU_LIST_MC, n_photons, h_g=10,
+                   describe="Sil/Gra/SiC MRN mix, Planck(3e4 K) emission, reflect + hg")
 
 
 def five_species_1e9(wl_list=None, grain_mix=(0.2, 0.2, 0.2, 0.2, 0.2)):
     """Config 4: five species (Sil, Gra, SiC, SUV, PAH), 1e9 photons per atmosphere, h_g = 500 pc.
     SUV and PAH have no counterpart in the reference's table code (extension)."""
     grain = tables.grain_data("mix", 0.001, 1, wl_list, grain_mix=grain_mix)
-    return _finish("five_species_1e9", grain, TAU_LIST_MC, 1000000000, h_g=500)
+    return _finish("five_species_1e9", grain, TAU_LIST_MC, 1000000000, h_g=500,
+                   describe="Sil/Gra/SiC/SUV/PAH equal mix, Planck(3e4 K) emission, reflect + hg")
 
 
 WORKLOADS = {"gray_1e5": gray_1e5, "sil_single_1e6": sil_single_1e6, "mix_2e7": mix_2e7,
