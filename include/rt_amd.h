@@ -177,6 +177,41 @@ int rt_replay(rt_ctx* ctx, const rt_params* p, int64_t n, int32_t max_draws, con
               const double* lambda, const double* g, const double* albedo, const double* scale,
               const double* mu0, rt_tallies* out, rt_photon_trace* per_photon);
 
+/* ---- table builder on the device (the step before the walk) ----
+ * One grain species as stored in a 'Draine data XXX' folder: per grain radius a table of
+ * w(micron) Q_abs Q_sca g with wavelength DESCENDING.  Columns of all sizes are concatenated;
+ * offset[i]..offset[i+1] are the rows of size i; sizes ascending in a[]. */
+typedef struct rt_grain_set {
+    int32_t n_sizes;
+    const double* a;       /* [n_sizes] */
+    const int32_t* offset; /* [n_sizes + 1] */
+    const double* wl;      /* [offset[n_sizes]] */
+    const double* q_abs;
+    const double* q_sca;
+    const double* g;
+} rt_grain_set;
+
+/* Host result arrays, each [n_wl] (any may be NULL), and three scalars. */
+typedef struct rt_grain_tables {
+    double* kappa_rp;  /* GetKappas: kappa_RP(lambda), read_BPASS.py:161 */
+    double* kappa_f;   /* GetKappas: kappa_F(lambda),  read_BPASS.py:162 */
+    double* sigma_abs; /* GetDraineAverage: Sigma_abs_av, MC code.py:308 */
+    double* sigma_sca; /* Sigma_scatt_av, MC code.py:309 */
+    double* g_av;      /* MC code.py:310 */
+    double* q_ext;     /* MC code.py:312 */
+    double kappa_av_rp; /* luminosity-weighted means, read_BPASS.py:159-160 */
+    double kappa_av_f;
+    double lum;         /* sum of the spectrum column, read_BPASS.py:136 */
+} rt_grain_tables;
+
+/* Interpolates every grain size to wl[n_wl] (np.interp semantics) and integrates over grain size
+ * (np.trapz) on the GPU.  Replaces GetKappas (read_BPASS.py:56-170; sizes in [grain_min, grain_max],
+ * `density` in g cm^-2 um^-1) and the commented GetDraineAverage recipe (MC code.py:270-324; all sizes,
+ * or the same size range if average_all_sizes == 0).  sed[n_wl] is the spectrum column (NULL = flat). */
+int rt_build_grain_tables(rt_ctx* ctx, const rt_grain_set* gs, double density, double grain_min, double grain_max,
+                          int32_t average_all_sizes, int32_t n_wl, const double* wl, const double* sed,
+                          rt_grain_tables* out);
+
 /* Test hook (no reference counterpart): applies the kernels' own fp64 ln(u) and cos(2*pi*u) to n host
  * values u in [0,1) so that their accuracy can be checked against a host math library. */
 int rt_selftest_math(rt_ctx* ctx, int64_t n, const double* u, double* out_log, double* out_cos);

@@ -48,13 +48,24 @@ class RtTallies(C.Structure):
     ]
 
 
+class RtGrainSet(C.Structure):
+    _fields_ = [("n_sizes", C.c_int32), ("a", c_double_p), ("offset", C.POINTER(C.c_int32)), ("wl", c_double_p),
+                ("q_abs", c_double_p), ("q_sca", c_double_p), ("g", c_double_p)]
+
+
+class RtGrainTables(C.Structure):
+    _fields_ = [("kappa_rp", c_double_p), ("kappa_f", c_double_p), ("sigma_abs", c_double_p), ("sigma_sca", c_double_p),
+                ("g_av", c_double_p), ("q_ext", c_double_p), ("kappa_av_rp", C.c_double), ("kappa_av_f", C.c_double),
+                ("lum", C.c_double)]
+
+
 class RtPhotonTrace(C.Structure):
     _fields_ = [("final_z", C.c_double), ("final_mu", C.c_double), ("fate", C.c_int32),
                 ("n_scatter", C.c_int32), ("n_draws", C.c_int32), ("pad_", C.c_int32)]
 
 
 EXPORTS = ["rt_abi_version", "rt_last_error", "rt_create", "rt_destroy", "rt_device_info", "rt_set_tables",
-           "rt_run", "rt_run_device", "rt_replay", "rt_kernel_time", "rt_selftest_math"]
+           "rt_run", "rt_run_device", "rt_replay", "rt_kernel_time", "rt_selftest_math", "rt_build_grain_tables"]
 
 _lib = None
 
@@ -80,6 +91,8 @@ def load_library(path=None):
     lib.rt_run_device.argtypes = [vp, C.POINTER(RtParams), vp, vp, vp, vp, vp]
     lib.rt_replay.argtypes = [vp, C.POINTER(RtParams), C.c_int64, C.c_int32, c_double_p, c_double_p, c_double_p,
                               c_double_p, c_double_p, c_double_p, C.POINTER(RtTallies), C.POINTER(RtPhotonTrace)]
+    lib.rt_build_grain_tables.argtypes = [vp, C.POINTER(RtGrainSet), C.c_double, C.c_double, C.c_double, C.c_int32,
+                                          C.c_int32, c_double_p, c_double_p, C.POINTER(RtGrainTables)]
     lib.rt_selftest_math.argtypes = [vp, C.c_int64, c_double_p, c_double_p, c_double_p]
     lib.rt_kernel_time.argtypes = [vp, c_double_p, C.POINTER(C.c_int64), C.c_int]
     for name in EXPORTS:

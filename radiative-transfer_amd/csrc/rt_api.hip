@@ -74,6 +74,11 @@ struct rt_ctx {
     // sweep workspace
     DevBuf<rt::AtmPlan> d_plan;
     DevBuf<uint32_t> d_prefix;
+    // pinned staging for the plan upload: the copy is asynchronous, `staged` says when the host side may be reused
+    void* h_stage = nullptr;
+    size_t h_stage_bytes = 0;
+    hipEvent_t staged = nullptr;
+    bool staged_pending = false;
     DevBuf<double> d_chunk_sums;
     DevBuf<unsigned int> d_next;
     // result staging for rt_run / rt_replay
@@ -200,9 +205,10 @@ int rt_create(rt_ctx** out, int device_id) {
                     arch.c_str());
     }
     e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->staged, hipEventDisableTiming);
     if (e != hipSuccess) {
         delete ctx;
-        return fail(RT_ERR_DEVICE, "hipStreamCreate: %s", hipGetErrorString(e));
+        return fail(RT_ERR_DEVICE, "hipStreamCreate / hipEventCreate: %s", hipGetErrorString(e));
     }
     // logarithm table for the kernels' ln(): c_j = 1 + (j + 1/2)/128, inv_c = fl(1/c_j), l = -ln(inv_c)
     std::vector<rt::LogTableEntry> tab(rt::kLogTableEntries);
@@ -235,6 +241,8 @@ int rt_destroy(rt_ctx* ctx) {
     ctx->d_log_table.release();
     ctx->d_plan.release();
     ctx->d_prefix.release();
+    if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+    if (ctx->staged) (void)hipEventDestroy(ctx->staged);
     ctx->d_chunk_sums.release();
     ctx->d_next.release();
     ctx->d_slab_sums.release();
@@ -347,8 +355,21 @@ int rt_run_device(rt_ctx* ctx, const rt_params* p, void* d_slab_sums, void* d_co
         const double cb = std::min(p->tau_atm[b], 4.0) * (double)p->n_photons[b];
         return ca > cb;
     });
-    std::vector<rt::AtmPlan> plan((size_t)p->n_atm);
-    std::vector<uint32_t> prefix((size_t)p->n_atm + 1);
+    const size_t plan_bytes = sizeof(rt::AtmPlan) * (size_t)p->n_atm;
+    const size_t prefix_bytes = sizeof(uint32_t) * ((size_t)p->n_atm + 1);
+    if (ctx->staged_pending) {  // the previous call's upload must have left the staging buffer
+        RT_HIP(hipEventSynchronize(ctx->staged));
+        ctx->staged_pending = false;
+    }
+    if (ctx->h_stage_bytes < plan_bytes + prefix_bytes) {
+        if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+        ctx->h_stage = nullptr;
+        ctx->h_stage_bytes = 0;
+        RT_HIP(hipHostMalloc(&ctx->h_stage, plan_bytes + prefix_bytes, hipHostMallocDefault));
+        ctx->h_stage_bytes = plan_bytes + prefix_bytes;
+    }
+    rt::AtmPlan* plan = static_cast<rt::AtmPlan*>(ctx->h_stage);
+    uint32_t* prefix = reinterpret_cast<uint32_t*>(static_cast<char*>(ctx->h_stage) + plan_bytes);
     unsigned long long slots = 0, items = 0;
     for (int k = 0; k < p->n_atm; ++k) {
         const int a = order[k];
@@ -368,14 +389,14 @@ int rt_run_device(rt_ctx* ctx, const rt_params* p, void* d_slab_sums, void* d_co
     }
     prefix[p->n_atm] = (uint32_t)items;
 
-    RT_HIP(ctx->d_plan.reserve(plan.size()));
-    RT_HIP(ctx->d_prefix.reserve(prefix.size()));
+    RT_HIP(ctx->d_plan.reserve((size_t)p->n_atm));
+    RT_HIP(ctx->d_prefix.reserve((size_t)p->n_atm + 1));
     RT_HIP(ctx->d_chunk_sums.reserve((size_t)slots * RT_NSUM));
     RT_HIP(ctx->d_next.reserve(1));
-    RT_HIP(hipMemcpyAsync(ctx->d_plan.p, plan.data(), sizeof(rt::AtmPlan) * plan.size(), hipMemcpyHostToDevice, stream));
-    RT_HIP(hipMemcpyAsync(ctx->d_prefix.p, prefix.data(), sizeof(uint32_t) * prefix.size(), hipMemcpyHostToDevice,
-                          stream));
-    RT_HIP(hipStreamSynchronize(stream));  // the host vectors go out of scope at return
+    RT_HIP(hipMemcpyAsync(ctx->d_plan.p, plan, plan_bytes, hipMemcpyHostToDevice, stream));
+    RT_HIP(hipMemcpyAsync(ctx->d_prefix.p, prefix, prefix_bytes, hipMemcpyHostToDevice, stream));
+    RT_HIP(hipEventRecord(ctx->staged, stream));
+    ctx->staged_pending = true;
 
     rt::Sweep sw;
     sw.plan = ctx->d_plan.p;
@@ -524,6 +545,111 @@ int rt_replay(rt_ctx* ctx, const rt_params* p, int64_t n, int32_t max_draws, con
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     cleanup();
     if (e != hipSuccess) return fail(RT_ERR_DEVICE, "replay failed: %s", hipGetErrorString(e));
+    return RT_OK;
+}
+
+int rt_build_grain_tables(rt_ctx* ctx, const rt_grain_set* gs, double density, double grain_min, double grain_max,
+                          int32_t average_all_sizes, int32_t n_wl, const double* wl, const double* sed,
+                          rt_grain_tables* out) {
+    if (!ctx || !gs || !out || !wl) return fail(RT_ERR_INVALID, "NULL argument");
+    if (gs->n_sizes < 1 || n_wl < 1 || !gs->a || !gs->offset || !gs->wl || !gs->q_abs || !gs->q_sca || !gs->g)
+        return fail(RT_ERR_INVALID, "empty grain set");
+    const int ns = gs->n_sizes;
+    for (int i = 0; i < ns; ++i) {
+        if (i && !(gs->a[i] > gs->a[i - 1])) return fail(RT_ERR_INVALID, "grain sizes must be strictly ascending");
+        if (gs->offset[i + 1] - gs->offset[i] < 2) return fail(RT_ERR_INVALID, "grain size %d has fewer than 2 rows", i);
+    }
+    // sizes inside [grain_min, grain_max] (read_BPASS.py:115) form a contiguous range of the ascending list
+    int lo_k = 0, hi_k = ns;
+    while (lo_k < ns && gs->a[lo_k] < grain_min) ++lo_k;
+    while (hi_k > lo_k && gs->a[hi_k - 1] > grain_max) --hi_k;
+    if (hi_k <= lo_k) return fail(RT_ERR_INVALID, "no grain size inside [grain_min, grain_max]");
+    const int lo_a = average_all_sizes ? 0 : lo_k, hi_a = average_all_sizes ? ns : hi_k;
+    RT_HIP(hipSetDevice(ctx->device));
+    const size_t rows = (size_t)gs->offset[ns];
+    std::vector<double> w15((size_t)ns), w35((size_t)ns);
+    for (int i = 0; i < ns; ++i) {
+        w15[i] = std::pow(gs->a[i], -1.5);
+        w35[i] = std::pow(gs->a[i], -3.5);
+    }
+    DevBuf<double> d_cols, d_small, d_wl, d_out;
+    DevBuf<int32_t> d_off;
+    auto cleanup = [&]() {
+        d_cols.release();
+        d_small.release();
+        d_wl.release();
+        d_out.release();
+        d_off.release();
+    };
+    hipError_t e = hipSuccess;
+    hipStream_t s = ctx->stream;
+    if ((e = d_cols.reserve(4 * rows)) != hipSuccess || (e = d_small.reserve(3 * (size_t)ns)) != hipSuccess ||
+        (e = d_wl.reserve((size_t)n_wl)) != hipSuccess || (e = d_out.reserve(6 * (size_t)n_wl)) != hipSuccess ||
+        (e = d_off.reserve((size_t)ns + 1)) != hipSuccess) {
+        cleanup();
+        return fail(RT_ERR_DEVICE, "device allocation failed: %s", hipGetErrorString(e));
+    }
+    const double* cols[4] = {gs->wl, gs->q_abs, gs->q_sca, gs->g};
+    for (int c = 0; c < 4 && e == hipSuccess; ++c)
+        e = hipMemcpyAsync(d_cols.p + c * rows, cols[c], sizeof(double) * rows, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_small.p, gs->a, sizeof(double) * ns, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_small.p + ns, w15.data(), sizeof(double) * ns, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_small.p + 2 * ns, w35.data(), sizeof(double) * ns, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_off.p, gs->offset, sizeof(int32_t) * (ns + 1), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_wl.p, wl, sizeof(double) * (size_t)n_wl, hipMemcpyHostToDevice, s);
+    rt::GrainSetDev dev;
+    dev.a = d_small.p;
+    dev.w15 = d_small.p + ns;
+    dev.w35 = d_small.p + 2 * ns;
+    dev.offset = d_off.p;
+    dev.wl = d_cols.p;
+    dev.q_abs = d_cols.p + rows;
+    dev.q_sca = d_cols.p + 2 * rows;
+    dev.g = d_cols.p + 3 * rows;
+    dev.n_sizes = ns;
+    EventPair* ev = nullptr;
+    if (e == hipSuccess) e = next_events(ctx, &ev);
+    if (e == hipSuccess) e = hipEventRecord(ev->a, s);
+    if (e == hipSuccess) e = rt::launch_grain_integrals(dev, n_wl, d_wl.p, lo_k, hi_k, lo_a, hi_a, d_out.p, s);
+    if (e == hipSuccess) e = hipEventRecord(ev->b, s);
+    std::vector<double> host(6 * (size_t)n_wl);
+    if (e == hipSuccess) e = hipMemcpyAsync(host.data(), d_out.p, sizeof(double) * host.size(), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    cleanup();
+    if (e != hipSuccess) return fail(RT_ERR_DEVICE, "table build failed: %s", hipGetErrorString(e));
+    // size-only normalisations (np.trapz over the same size ranges) and the wavelength integrals, on the host
+    const double pi = 3.141592653589793;
+    auto trapz_sizes = [&](int lo, int hi, auto f) {
+        if (hi - lo == 1) return f(lo);
+        double acc = 0.0;
+        for (int i = lo + 1; i < hi; ++i) acc += (gs->a[i] - gs->a[i - 1]) * (f(i) + f(i - 1)) / 2.0;
+        return acc;
+    };
+    const double mass = trapz_sizes(lo_k, hi_k, [&](int i) { return 4 * pi / 3 * std::pow(gs->a[i], -0.5) * density; });
+    const double norm = hi_a - lo_a == 1 ? 1.0 : trapz_sizes(lo_a, hi_a, [&](int i) { return w35[i]; });
+    const size_t n = (size_t)n_wl;
+    double lum = 0.0;
+    for (size_t j = 0; j < n; ++j) lum += sed ? sed[j] : 1.0;
+    double int_rp = 0.0, int_f = 0.0;
+    for (size_t j = 1; j < n; ++j) {
+        const double l0 = sed ? sed[j - 1] : 1.0, l1 = sed ? sed[j] : 1.0, d = wl[j] - wl[j - 1];
+        int_rp += d * (host[j] * l1 + host[j - 1] * l0) / 2.0;
+        int_f += d * (host[n + j] * l1 + host[n + j - 1] * l0) / 2.0;
+    }
+    out->kappa_av_rp = int_rp * 1e4 / mass / lum;
+    out->kappa_av_f = int_f * 1e4 / mass / lum;
+    out->lum = lum;
+    const bool one_avg = hi_a - lo_a == 1;
+    for (size_t j = 0; j < n; ++j) {
+        if (out->kappa_rp) out->kappa_rp[j] = host[j] / mass;
+        if (out->kappa_f) out->kappa_f[j] = host[n + j] / mass;
+        // one size: pi a^2 Q and the tabulated g, Q_ext
+        const double area = one_avg ? pi * (gs->a[lo_a] * gs->a[lo_a]) : 0.0;
+        if (out->sigma_abs) out->sigma_abs[j] = one_avg ? area * host[2 * n + j] : host[2 * n + j] / norm;
+        if (out->sigma_sca) out->sigma_sca[j] = one_avg ? area * host[3 * n + j] : host[3 * n + j] / norm;
+        if (out->g_av) out->g_av[j] = host[4 * n + j] / norm;
+        if (out->q_ext) out->q_ext[j] = host[5 * n + j] / norm;
+    }
     return RT_OK;
 }
 

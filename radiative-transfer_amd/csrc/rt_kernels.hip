@@ -400,7 +400,93 @@ __global__ void selftest_math_kernel(const LogTableEntry* __restrict__ table, lo
     }
 }
 
+// ---------------------------------------------------------------------------
+// Grain-size integration of the Draine tables: one thread per output wavelength.
+// For every grain size the three tabulated columns are interpolated linearly to the output
+// wavelength exactly as np.interp does on the flipped (ascending) columns (read_BPASS.py:94-96:
+// clamped outside the tabulated range, slope * (x - x_k) + y_k inside), and the size integrals of
+// GetKappas (read_BPASS.py:159-162) and GetDraineAverage (MC code.py:306-312) are accumulated with the
+// trapezoid rule over consecutive sizes (np.trapz).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void interp3(const double* __restrict__ xw, const double* __restrict__ ya,
+                                        const double* __restrict__ ys, const double* __restrict__ yg, int rows, double x,
+                                        double& qa, double& qs, double& gg) {
+    // columns are stored descending in wavelength: ascending index r corresponds to stored row rows-1-r
+    const double x_first = xw[rows - 1], x_last = xw[0];
+    if (x <= x_first) {  // np.interp: left clamp (also the exact hit on the first abscissa)
+        qa = ya[rows - 1];
+        qs = ys[rows - 1];
+        gg = yg[rows - 1];
+        return;
+    }
+    if (x >= x_last) {
+        qa = ya[0];
+        qs = ys[0];
+        gg = yg[0];
+        return;
+    }
+    int lo = 0, hi = rows - 1;  // ascending indices with xasc[lo] <= x < xasc[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (xw[rows - 1 - mid] <= x)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    const int k0 = rows - 1 - lo, k1 = rows - 1 - hi;
+    const double x0 = xw[k0], dx = xw[k1] - x0, t = x - x0;
+    qa = (ya[k1] - ya[k0]) / dx * t + ya[k0];
+    qs = (ys[k1] - ys[k0]) / dx * t + ys[k0];
+    gg = (yg[k1] - yg[k0]) / dx * t + yg[k0];
+}
+
+__global__ __launch_bounds__(256) void grain_integrals_kernel(const GrainSetDev gs, const int n_wl,
+                                                              const double* __restrict__ wl, const int lo_k,
+                                                              const int hi_k, const int lo_a, const int hi_a,
+                                                              double* __restrict__ out) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_wl) return;
+    const double x = wl[j];
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    double prev[6] = {0, 0, 0, 0, 0, 0};
+    double a_prev = 0.0;
+    const int first = lo_k < lo_a ? lo_k : lo_a, last = hi_k > hi_a ? hi_k : hi_a;
+    for (int i = first; i < last; ++i) {
+        const int off = gs.offset[i], rows = gs.offset[i + 1] - off;
+        double qa, qs, gg;
+        interp3(gs.wl + off, gs.q_abs + off, gs.q_sca + off, gs.g + off, rows, x, qa, qs, gg);
+        const double a = gs.a[i];
+        const double pi = 3.141592653589793;
+        const double w15 = gs.w15[i], w35 = gs.w35[i];
+        double cur[6];
+        cur[0] = (qa + (1.0 - gg) * qs) * w15 * pi;  // Q_ext_RP * a**-1.5 * pi, read_BPASS.py:100,161
+        cur[1] = (qa + qs) * w15 * pi;               // Q_ext_F  * a**-1.5 * pi, read_BPASS.py:99,162
+        cur[2] = w15 * pi * qa;                      // a**(-1.5) * pi * Q_abs,  MC code.py:308
+        cur[3] = w15 * pi * qs;
+        cur[4] = w35 * gg;
+        cur[5] = w35 * (qa + qs);
+        const double da = a - a_prev;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const int lo = k < 2 ? lo_k : lo_a, hi = k < 2 ? hi_k : hi_a;
+            if (i > lo && i < hi) acc[k] += da * (cur[k] + prev[k]) / 2.0;
+            // a single size: no integral; opacities keep the integrand, averages the tabulated values
+            if (hi - lo == 1 && i == lo) acc[k] = k < 2 ? cur[k] : (k == 2 ? qa : k == 3 ? qs : k == 4 ? gg : qa + qs);
+            prev[k] = cur[k];
+        }
+        a_prev = a;
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) out[(size_t)k * n_wl + j] = acc[k];
+}
+
 // ------------------------------- launchers -------------------------------
+hipError_t launch_grain_integrals(const GrainSetDev& gs, int n_wl, const double* d_wl, int lo_k, int hi_k, int lo_a,
+                                  int hi_a, double* d_out, hipStream_t stream) {
+    grain_integrals_kernel<<<(n_wl + 255) / 256, 256, 0, stream>>>(gs, n_wl, d_wl, lo_k, hi_k, lo_a, hi_a, d_out);
+    return hipGetLastError();
+}
+
 hipError_t launch_selftest_math(const LogTableEntry* d_table, long long n, const double* d_u, double* d_log,
                                 double* d_cos, hipStream_t stream) {
     selftest_math_kernel<<<(unsigned int)((n + 255) / 256), 256, 0, stream>>>(d_table, n, d_u, d_log, d_cos);

@@ -51,3 +51,26 @@ hipError_t launch_selftest_math(const LogTableEntry* d_table, long long n, const
                                 double* d_cos, hipStream_t stream);
 
 }  // namespace rt
+
+// ---- device table builder (grain-size integration of the Draine tables) ----
+namespace rt {
+
+struct GrainSetDev {
+    const double* a;        // [n_sizes] grain radii, ascending
+    const double* w15;      // [n_sizes] a^-1.5 (host pow, like NumPy's)
+    const double* w35;      // [n_sizes] a^-3.5
+    const int32_t* offset;  // [n_sizes + 1] start of each size's rows in the concatenated columns
+    const double* wl;       // concatenated per-size wavelength columns, DESCENDING as in the files
+    const double* q_abs;
+    const double* q_sca;
+    const double* g;
+    int32_t n_sizes;
+};
+
+// out[k * n_wl + j], k = 0..5: int Q_ext_RP a^-1.5 pi da, int Q_ext_F a^-1.5 pi da  (sizes in [lo_k, hi_k))
+//                              int Q_abs a^-1.5 pi da, int Q_sca a^-1.5 pi da, int g a^-3.5 da,
+//                              int (Q_abs+Q_sca) a^-3.5 da                          (sizes in [lo_a, hi_a))
+hipError_t launch_grain_integrals(const GrainSetDev& gs, int n_wl, const double* d_wl, int lo_k, int hi_k, int lo_a,
+                                  int hi_a, double* d_out, hipStream_t stream);
+
+}  // namespace rt

@@ -167,6 +167,28 @@ class Engine:
                                         C.byref(res._c), trace.ctypes.data_as(C.POINTER(abi.RtPhotonTrace))))
         return res, trace
 
+    def build_grain_tables(self, a, columns, density, grain_min, grain_max, wl, sed=None, average_all_sizes=True):
+        """Grain-size integration on the GPU.  `a` ascending grain radii; `columns` = (wl, q_abs, q_sca, g), each a
+        list with one array per size (stored order, wavelength descending).  Returns a dict with the columns of
+        GetKappas / GetDraineAverage on `wl`."""
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        rows = np.array([len(c) for c in columns[0]], dtype=np.int64)
+        offset = np.concatenate([[0], np.cumsum(rows)]).astype(np.int32)
+        cols = [np.ascontiguousarray(np.concatenate(c), dtype=np.float64) for c in columns]
+        wl = np.ascontiguousarray(wl, dtype=np.float64)
+        sed_a = None if sed is None else np.ascontiguousarray(sed, dtype=np.float64)
+        gs = abi.RtGrainSet(len(a), _dp(a), offset.ctypes.data_as(C.POINTER(C.c_int32)), *[_dp(c) for c in cols])
+        out = {k: np.empty(len(wl)) for k in ("Kappa_RP", "Kappa_F", "Sigma-Abs", "Sigma-Scatt", "g", "Q_ext")}
+        res = abi.RtGrainTables(*[_dp(out[k]) for k in ("Kappa_RP", "Kappa_F", "Sigma-Abs", "Sigma-Scatt", "g", "Q_ext")],
+                                0.0, 0.0, 0.0)
+        self._check(self._lib.rt_build_grain_tables(self._ctx, C.byref(gs), float(density), float(grain_min),
+                                                    float(grain_max), int(bool(average_all_sizes)), len(wl), _dp(wl),
+                                                    None if sed_a is None else _dp(sed_a), C.byref(res)))
+        out.update(kappa_av_RP=res.kappa_av_rp, kappa_av_F=res.kappa_av_f, L=res.lum, WL=wl)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            out["Albedo"] = out["Sigma-Scatt"] / (out["Sigma-Scatt"] + out["Sigma-Abs"])  # MC code.py:320
+        return out
+
     def selftest_math(self, u):
         """The device's ln(u) and cos(2 pi u) for u in [0,1) (test hook)."""
         u = np.ascontiguousarray(u, dtype=np.float64)

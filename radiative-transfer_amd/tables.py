@@ -176,13 +176,25 @@ def get_kappas(gs, grain_min, grain_max, wl_list, sed=None):
     return dict(kappa_av_RP=kappa_av_rp, kappa_av_F=kappa_av_f, Kappa_RP=kappa_rp, Kappa_F=kappa_f, L=L, a=a)
 
 
+def _reference_index(wl_list, wl_ref):
+    index = np.asarray(wl_list).round(decimals=4) == wl_ref
+    if index.sum() != 1:
+        raise ValueError(f"wl_ref={wl_ref} must match exactly one grid wavelength")
+    return index
+
+
+def grain_tables_device(engine, gs, grain_min, grain_max, wl_list, sed=None, average_over_all_sizes=True):
+    """get_kappas + get_draine_average of one species in one GPU pass (Engine.build_grain_tables): keys
+    Kappa_RP, Kappa_F, kappa_av_RP, kappa_av_F, L, Sigma-Abs, Sigma-Scatt, g, Albedo, Q_ext, WL."""
+    return engine.build_grain_tables(gs.a, (gs.wl, gs.q_abs, gs.q_sca, gs.g), DENSITY[gs.species], grain_min, grain_max,
+                                     np.asarray(wl_list, dtype=float), sed, average_over_all_sizes)
+
+
 def get_tau_scaling(gs, grain_min, grain_max, wl_list, wl_ref=0.656, sed=None):
     """Columns WL, Kappa_RP, Kappa_F, Scale, ExtScale of GetTauScaling's frame (read_BPASS.py:172-184)."""
     wl_list = np.asarray(wl_list, dtype=float)
     k = get_kappas(gs, grain_min, grain_max, wl_list, sed)
-    index = wl_list.round(decimals=4) == wl_ref
-    if index.sum() != 1:
-        raise ValueError(f"wl_ref={wl_ref} must match exactly one grid wavelength")
+    index = _reference_index(wl_list, wl_ref)
     return dict(WL=wl_list, Kappa_RP=k["Kappa_RP"], Kappa_F=k["Kappa_F"], Scale=k["Kappa_RP"] / k["Kappa_RP"][index],
                 ExtScale=k["Kappa_F"] / k["Kappa_F"][index], kappa_av_RP=k["kappa_av_RP"], kappa_av_F=k["kappa_av_F"])
 
@@ -219,20 +231,27 @@ def get_draine_average(gs, wavelengths, grain_min=None, grain_max=None):
 # Grain_data as RunPhotons sees it
 # --------------------------------------------------------------------------------------
 def grain_data(grain_type="mix", grain_min=0.001, grain_max=1, wl_list=None, wl_ref=0.656,
-               grain_mix=(0.5, 0.45, 0.05), sed=None, folders=None, average_over_all_sizes=True):
+               grain_mix=(0.5, 0.45, 0.05), sed=None, folders=None, average_over_all_sizes=True, engine=None):
     """Columns WL, g, Albedo, Scale (+ Kappa_RP, Kappa_F, ExtScale) on wl_list.
 
     grain_type 'mix' blends the Sil, Gra, SiC frames LINEARLY with grain_mix, as
     GetGrainKappas does (MC code.py:210-211); any other value is one species.  The averages
     g / Albedo come from get_draine_average, the opacities from get_tau_scaling, and the two
     are joined on WL rounded to 4 decimals (MC code.py:1226-1229).  A longer grain_mix with
-    species names ('Sil','Gra','SiC','SUV','PAH' order) is an extension."""
+    species names ('Sil','Gra','SiC','SUV','PAH' order) is an extension.  With `engine` (an Engine on a
+    GPU) the interpolation and the grain-size integrals run on the device (grain_tables_device)."""
     wl_list = reference_wavelength_grid() if wl_list is None else np.asarray(wl_list, dtype=float)
     folders = folders or {}
     names = ["Sil", "Gra", "SiC", "SUV", "PAH"]
 
     def one(species):
         gs = load_species(species, folders.get(species))
+        if engine is not None:
+            t = grain_tables_device(engine, gs, grain_min, grain_max, wl_list, sed, average_over_all_sizes)
+            index = _reference_index(wl_list, wl_ref)
+            return {"g": t["g"], "Albedo": t["Albedo"], "Scale": t["Kappa_RP"] / t["Kappa_RP"][index],
+                    "Kappa_RP": t["Kappa_RP"], "Kappa_F": t["Kappa_F"], "ExtScale": t["Kappa_F"] / t["Kappa_F"][index],
+                    "Q_ext": t["Q_ext"]}
         av = get_draine_average(gs, wl_list, None if average_over_all_sizes else grain_min,
                                 None if average_over_all_sizes else grain_max)
         ts = get_tau_scaling(gs, grain_min, grain_max, wl_list, wl_ref, sed)
