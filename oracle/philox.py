@@ -11,12 +11,12 @@ Stream layout shared by every implementation in this repository:
     key     = (seed_lo, seed_hi)
     counter = (photon_id_lo, photon_id_hi, block, atmosphere_index)
     draw j of a photon's walk stream -> block j >> 1, words (2*(j&1), 2*(j&1)+1)
-    uniform = ((w_a >> 5) * 2**26 + (w_b >> 6)) / 2**53      in [0, 1)
+    uniform = ((w_a << 20) | (w_b >> 12)) / 2**52            in [0, 1)
 
-The uniform construction is the 53-bit one NumPy's legacy ``random.rand`` uses
-(two 32-bit words -> 27 + 26 bits), so the set of representable draws is the
-same as in the reference scripts, which call ``np.random.rand``
-(MC code.py:496, :479, :436-437).
+The uniform takes the top 52 bits of the word pair as the fraction of a double in
+[1, 2) and subtracts 1: every multiple of 2**-52 in [0, 1) is equally likely.  (The
+reference scripts call ``np.random.rand``, MC code.py:496, :479, :436-437, whose
+draws are the multiples of 2**-53.)
 """
 import numpy as np
 
@@ -47,11 +47,12 @@ def philox4x32_10(c0, c1, c2, c3, k0, k1):
     return c0, c1, c2, c3
 
 
-def u53(wa, wb):
-    """Two 32-bit words -> double in [0,1) with 53 random bits."""
-    a = np.asarray(wa, dtype=np.uint64) >> np.uint64(5)
-    b = np.asarray(wb, dtype=np.uint64) >> np.uint64(6)
-    return (a.astype(np.float64) * 67108864.0 + b.astype(np.float64)) / 9007199254740992.0
+def u52(wa, wb):
+    """Two 32-bit words -> double in [0,1) with 52 random bits (exact: a 52-bit integer / 2**52)."""
+    a = np.asarray(wa, dtype=np.uint64) & MASK32
+    b = np.asarray(wb, dtype=np.uint64) & MASK32
+    k = (a << np.uint64(20)) | (b >> np.uint64(12))
+    return k.astype(np.float64) / 4503599627370496.0
 
 
 def block_uniforms(photon_id, block, atm, seed):
@@ -59,7 +60,7 @@ def block_uniforms(photon_id, block, atm, seed):
     pid = np.asarray(photon_id, dtype=np.uint64)
     w = philox4x32_10(pid & MASK32, pid >> np.uint64(32), block, atm,
                       seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
-    return u53(w[0], w[1]), u53(w[2], w[3])
+    return u52(w[0], w[1]), u52(w[2], w[3])
 
 
 def walk_uniform(photon_id, j, atm, seed):

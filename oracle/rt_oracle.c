@@ -54,8 +54,8 @@ void ora_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-static double u53(uint32_t a, uint32_t b) {
-    return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) / 9007199254740992.0;
+static double u52(uint32_t a, uint32_t b) {
+    return (double)(((uint64_t)a << 20) | (uint64_t)(b >> 12)) / 4503599627370496.0;
 }
 
 static void block_uniforms(uint64_t id, uint32_t block, uint32_t atm, uint64_t seed, double* ua, double* ub) {
@@ -63,8 +63,8 @@ static void block_uniforms(uint64_t id, uint32_t block, uint32_t atm, uint64_t s
     uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
     uint32_t w[4];
     ora_philox4x32_10(ctr, key, w);
-    *ua = u53(w[0], w[1]);
-    *ub = u53(w[2], w[3]);
+    *ua = u52(w[0], w[1]);
+    *ub = u52(w[2], w[3]);
 }
 
 /* ---------------- emission law: Walker/Vose alias table ----------------

@@ -57,9 +57,16 @@ __device__ __forceinline__ PhiloxOut philox4x32_10(uint32_t c0, uint32_t c1, uin
     return {c0, c1, c2, c3};
 }
 
-// 53-bit uniform in [0,1): the construction NumPy's legacy random.rand uses.
-__device__ __forceinline__ double u53(uint32_t a, uint32_t b) {
+// Uniform in [0,1) with 52 random bits: the top 52 bits of a:b become the fraction of a double in [1,2),
+// minus 1 (exact).  Two funnel shifts and one subtraction; values are the multiples of 2^-52.
+__device__ __forceinline__ double u52(uint32_t a, uint32_t b) {
+#ifdef RT_UNIFORM_53
     return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) * (1.0 / 9007199254740992.0);
+#else
+    const uint32_t hi = __builtin_amdgcn_alignbit(0x3FFu, a, 12);  // 0x3FF00000 | (a >> 12)
+    const uint32_t lo = __builtin_amdgcn_alignbit(a, b, 12);       // (a << 20) | (b >> 12)
+    return __hiloint2double((int)hi, (int)lo) - 1.0;
+#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -134,15 +141,15 @@ struct PhiloxSrc {
     __device__ __forceinline__ int pair(double& a, double& b) {
         const PhiloxOut o = philox4x32_10(id_lo, id_hi, blk, atm, k0, k1);
         ++blk;
-        a = u53(o.w0, o.w1);
-        b = u53(o.w2, o.w3);
+        a = u52(o.w0, o.w1);
+        b = u52(o.w2, o.w3);
         return 2;
     }
     __device__ __forceinline__ void emit_pair(double& a, double& b) {
         const PhiloxOut o = philox4x32_10(id_lo, id_hi, kEmitBlock + n_emit, atm, k0, k1);
         ++n_emit;
-        a = u53(o.w0, o.w1);
-        b = u53(o.w2, o.w3);
+        a = u52(o.w0, o.w1);
+        b = u52(o.w2, o.w3);
     }
     __device__ __forceinline__ void used(int) {}
 };
@@ -363,7 +370,7 @@ __device__ __forceinline__ int scatter(const Cfg& cfg, Photon& ph, Src& src, dou
     } else if (mu_old == -1.0) {
         mu_new = -mu_prime;
     } else {
-        mu_new = -sqrt((1.0 - mu_old * mu_old) * (1.0 - mu_prime * mu_prime)) * cos_2pi(u_phi) + mu_old * mu_prime;
+        mu_new = -sqrt_unit((1.0 - mu_old * mu_old) * (1.0 - mu_prime * mu_prime)) * cos_2pi(u_phi) + mu_old * mu_prime;
     }
     ph.mu = mu_new;
     ph.n_scatter++;

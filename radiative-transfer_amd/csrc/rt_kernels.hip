@@ -218,8 +218,8 @@ __global__ __launch_bounds__(kWalkBlock) void walk_kernel(const Cfg cfg, const S
 // flight -- lanes whose photon ended (they need a new photon) and lanes whose photon goes on to
 // scatter -- share ONE Philox call: each lane feeds its own counter (emission block of the new
 // photon id, or the scattering block of the current one) and the 128 output bits are then read
-// as the emission draws or as (azimuth, cosine).  The table record of the new photons is
-// requested before the scattering arithmetic runs, so the gather latency hides under it.
+// as the emission draws or as (azimuth, cosine).  The alias-table entry of the new photons is
+// requested before the scattering arithmetic runs, so the first gather's latency hides under it.
 __global__ __launch_bounds__(kWalkBlock) void walk_fast_kernel(const Cfg cfg, const Sweep sw,
                                                                 unsigned int* __restrict__ d_next,
                                                                 double* __restrict__ d_chunk_sums,
@@ -270,23 +270,33 @@ __global__ __launch_bounds__(kWalkBlock) void walk_fast_kernel(const Cfg cfg, co
                 // ---- one Philox call: emission block for fresh lanes, scattering block otherwise ----
                 const uint32_t block = fresh ? kEmitBlock : src.blk;
                 const PhiloxOut o = philox4x32_10(src.id_lo, src.id_hi, block, src.atm, src.k0, src.k1);
-                const double ua = u53(o.w0, o.w1);
-                const double ub = u53(o.w2, o.w3);
-                const int idx = fresh ? sample_index(cfg, ua) : 0;
-                const TableRec rec = load_record(cfg, idx);  // scattering lanes read record 0 (one line, broadcast)
+                const double ua = u52(o.w0, o.w1);
+                const double ub = u52(o.w2, o.w3);
+                // alias entry of the new photons' bucket, requested now; scattering lanes read entry 0 (broadcast)
+                const double xb = ua * (double)cfg.n_wl;
+                int bucket = (int)xb;
+                bucket = bucket < cfg.n_wl ? bucket : cfg.n_wl - 1;
+                bucket = fresh ? bucket : 0;
+                const uint4 raw = *reinterpret_cast<const uint4*>(&cfg.alias[bucket]);
                 if (!fresh) {
                     ++src.blk;
                     scatter<true>(cfg, ph, src, ua, ub, 2, acc, hist);
-                } else {
+                }
+                const double prob = __hiloint2double((int)raw.y, (int)raw.x);
+                int idx = (xb - (double)bucket) < prob ? bucket : (int)raw.z;
+                idx = cfg.mono_index >= 0 ? cfg.mono_index : idx;
+                idx = fresh ? idx : 0;
+                const TableRec rec = load_record(cfg, idx);
+                const bool guard = !fresh && ph.iter >= (uint32_t)cfg.max_events;
+                double u_step, u_abs;
+                src.pair(u_step, u_abs);
+                if (fresh) {
                     set_constants(cfg, tau, rec, cfg.rand_mu ? ub : 1.0, ph);
                     start_photon(ph, acc);
                     alive = true;
                 }
-                // ---- flight: step, tests, absorption ----
                 int fate = RT_FATE_GUARD;
-                if (ph.iter < (uint32_t)cfg.max_events) {
-                    double u_step, u_abs;
-                    src.pair(u_step, u_abs);
+                if (!guard) {
                     int n_used = 0;
                     fate = fly<true>(cfg, ph, u_step, u_abs, 2, false, acc, hist, no_reemit, n_used);
                 }
@@ -389,7 +399,8 @@ __global__ __launch_bounds__(kWalkBlock) void replay_kernel(const Cfg cfg, const
 
 // The kernels' own ln() and cos(2 pi u) applied element-wise (test hook).
 __global__ void selftest_math_kernel(const LogTableEntry* __restrict__ table, long long n, const double* __restrict__ u,
-                                     double* __restrict__ out_log, double* __restrict__ out_cos) {
+                                     double* __restrict__ out_log, double* __restrict__ out_cos,
+                                     double* __restrict__ out_sqrt) {
     __shared__ LogTableEntry lds_table[kLogTableEntries];
     for (int k = threadIdx.x; k < kLogTableEntries; k += blockDim.x) lds_table[k] = table[k];
     __syncthreads();
@@ -397,6 +408,7 @@ __global__ void selftest_math_kernel(const LogTableEntry* __restrict__ table, lo
     if (i < n) {
         out_log[i] = log_unit(u[i], lds_table);
         out_cos[i] = cos_2pi(u[i]);
+        out_sqrt[i] = sqrt_unit(u[i]);
     }
 }
 
@@ -488,8 +500,8 @@ hipError_t launch_grain_integrals(const GrainSetDev& gs, int n_wl, const double*
 }
 
 hipError_t launch_selftest_math(const LogTableEntry* d_table, long long n, const double* d_u, double* d_log,
-                                double* d_cos, hipStream_t stream) {
-    selftest_math_kernel<<<(unsigned int)((n + 255) / 256), 256, 0, stream>>>(d_table, n, d_u, d_log, d_cos);
+                                double* d_cos, double* d_sqrt, hipStream_t stream) {
+    selftest_math_kernel<<<(unsigned int)((n + 255) / 256), 256, 0, stream>>>(d_table, n, d_u, d_log, d_cos, d_sqrt);
     return hipGetLastError();
 }
 

@@ -76,4 +76,28 @@ __device__ __forceinline__ double cos_2pi(double u) {
     return ((n + 1) & 2) ? -v : v;  // q = 0: c, 1: -s, 2: -c, 3: s, 4: c
 }
 
+// ---------------------------------------------------------------------------
+// sqrt(x) for x = 0 or a normal x that needs no rescaling (2^-500 < x < 2^500): the product
+// (1 - mu^2)(1 - mu'^2) of RotateIntoLabFrame lies in [0, 1] and is either 0 or >= 2^-106.
+// Reciprocal-square-root seed, one coupled Goldschmidt step and two residual corrections: the
+// sequence of the general fp64 square root without its range scaling.  NaN for x < 0.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double sqrt_unit(double x) {
+#ifdef RT_SQRT_GENERAL
+    return sqrt(x);
+#else
+    const double r = __builtin_amdgcn_rsq(x);
+    double y = x * r;
+    double h = r * 0.5;
+    const double e = fma(-h, y, 0.5);
+    y = fma(y, e, y);
+    h = fma(h, e, h);
+    double d = fma(-y, y, x);
+    y = fma(d, h, y);
+    d = fma(-y, y, x);
+    y = fma(d, h, y);
+    return x == 0.0 ? 0.0 : y;
+#endif
+}
+
 }  // namespace rt

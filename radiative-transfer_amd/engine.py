@@ -190,11 +190,11 @@ class Engine:
         return out
 
     def selftest_math(self, u):
-        """The device's ln(u) and cos(2 pi u) for u in [0,1) (test hook)."""
+        """The device's ln(u), cos(2 pi u) and sqrt(u) for u in [0,1) (test hook)."""
         u = np.ascontiguousarray(u, dtype=np.float64)
-        out_log, out_cos = np.empty_like(u), np.empty_like(u)
-        self._check(self._lib.rt_selftest_math(self._ctx, len(u), _dp(u), _dp(out_log), _dp(out_cos)))
-        return out_log, out_cos
+        out_log, out_cos, out_sqrt = np.empty_like(u), np.empty_like(u), np.empty_like(u)
+        self._check(self._lib.rt_selftest_math(self._ctx, len(u), _dp(u), _dp(out_log), _dp(out_cos), _dp(out_sqrt)))
+        return out_log, out_cos, out_sqrt
 
     def kernel_time(self, reset=False):
         ms, n = C.c_double(), C.c_int64()

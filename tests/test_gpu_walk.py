@@ -124,13 +124,13 @@ def test_errors(rt, engine):
 
 
 def test_device_math_accuracy(engine):
-    """The kernels' own ln(u) and cos(2 pi u) against NumPy in extended precision."""
+    """The kernels' own ln(u), cos(2 pi u) and sqrt(u) against NumPy (extended precision for ln and cos)."""
     rng = np.random.default_rng(7)
     u = np.concatenate([rng.random(200000), 2.0 ** -rng.integers(1, 53, 2000) * rng.random(2000),
                         1 - 2.0 ** -rng.integers(1, 53, 2000), [2.0 ** -53, 0.25, 0.5, 0.75, 1 - 2.0 ** -53, 0.125]])
     u = np.floor(u * 2.0 ** 53) / 2.0 ** 53
     u = u[u > 0]
-    got_log, got_cos = engine.selftest_math(u)
+    got_log, got_cos, got_sqrt = engine.selftest_math(u)
     ul = u.astype(np.longdouble)
     want_log = np.log(ul)
     err = np.abs(got_log.astype(np.longdouble) - want_log)
@@ -139,5 +139,9 @@ def test_device_math_accuracy(engine):
     assert float(np.max(np.abs(got_cos.astype(np.longdouble) - want_cos))) < 3e-16
     # and against what the reference computes: np.cos(2*np.pi*u) with the product rounded to double
     assert float(np.max(np.abs(got_cos - np.cos(2 * np.pi * u)))) < 1.2e-15
-    lz, _ = engine.selftest_math(np.array([0.0]))
-    assert np.isneginf(lz[0])
+    # the square root is the correctly rounded one on its whole domain, products of two (1 - mu^2) included
+    assert np.array_equal(got_sqrt, np.sqrt(u))
+    tiny = np.concatenate([2.0 ** -rng.integers(53, 107, 5000) * (1 + rng.random(5000)), [2.0 ** -106, 1.0, 4.0]])
+    assert np.array_equal(engine.selftest_math(tiny)[2], np.sqrt(tiny))
+    lz, _, sz = engine.selftest_math(np.array([0.0]))
+    assert np.isneginf(lz[0]) and sz[0] == 0.0

@@ -34,10 +34,14 @@ def test_philox_known_answers(c_oracle):
         assert [int(x) for x in got] == want
 
 
-def test_uniform_is_53_bit_and_below_one():
+def test_uniform_is_52_bit_and_below_one(c_oracle):
     u = philox.walk_matrix(1000, 8, 3, 12345)
     assert u.min() >= 0.0 and u.max() < 1.0
-    assert np.all(u * 2.0 ** 53 == np.floor(u * 2.0 ** 53))
+    assert np.all(u * 2.0 ** 52 == np.floor(u * 2.0 ** 52))
+    assert np.any(u * 2.0 ** 51 != np.floor(u * 2.0 ** 51))  # the last bit is used
+    # extremes of the word pair
+    assert philox.u52(0xFFFFFFFF, 0xFFFFFFFF) == 1.0 - 2.0 ** -52 and philox.u52(0, 0xFFF) == 0.0
+    assert philox.u52(0x80000000, 0) == 0.5 and philox.u52(0, 0x1000) == 2.0 ** -52
 
 
 @pytest.mark.parametrize("name", [str(n) for n in REPLAY["names"]])

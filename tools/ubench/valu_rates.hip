@@ -33,6 +33,13 @@ __global__ __launch_bounds__(256) void k(uint64_t* out, unsigned long long* clk)
             if (OP == 4) a[i] = __umulhi(a[i], 0xCD9E8D57u) + 7u;                                 // v_mul_hi_u32 (+add)
             if (OP == 5) d[i] = d[i] + 1e-9;                                                      // v_add_f64
             if (OP == 6) a[i] = __mul24((int)(a[i] & 0xFFFFFF), 0x9E3779) + 3u;                   // v_mad_u32_u24
+            if (OP == 7) { d[i] = (double)a[i]; a[i] = (uint32_t)__double2hiint(d[i]); }          // v_cvt_f64_u32
+            if (OP == 8) d[i] = __builtin_amdgcn_ldexp(d[i], (int)(a[i] & 1u));                    // v_ldexp_f64 (+v_and hoisted)
+            if (OP == 9) d[i] = __builtin_amdgcn_rcp(d[i]);                                       // v_rcp_f64
+            if (OP == 10) d[i] = __builtin_amdgcn_rsq(d[i]);                                      // v_rsq_f64
+            if (OP == 11) d[i] = 1.0000001 / d[i];                                                // IEEE division sequence
+            if (OP == 12) d[i] = __builtin_sqrt(d[i]) + 1.0;                                      // IEEE sqrt sequence + add
+            if (OP == 13) { a[i] = (uint32_t)(int)d[i]; d[i] = __hiloint2double((int)(a[i] | 0x3ff00000u), (int)a[i]); }  // v_cvt_i32_f64 + or
         }
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -73,5 +80,12 @@ int main() {
     run<3>("v_mul_lo_u32 + v_add", 2, d_out, d_clk);
     run<4>("v_mul_hi_u32 + v_add", 2, d_out, d_clk);
     run<6>("v_mul_u32_u24 + v_add", 2, d_out, d_clk);
+    run<7>("v_cvt_f64_u32", 1, d_out, d_clk);
+    run<8>("v_ldexp_f64", 1, d_out, d_clk);
+    run<9>("v_rcp_f64", 1, d_out, d_clk);
+    run<10>("v_rsq_f64", 1, d_out, d_clk);
+    run<11>("fp64 division (sequence)", 1, d_out, d_clk);
+    run<12>("fp64 sqrt (sequence) + add", 1, d_out, d_clk);
+    run<13>("v_cvt_i32_f64 + v_or", 2, d_out, d_clk);
     return 0;
 }
