@@ -34,26 +34,50 @@ FP64_OPS_PER_EVENT = 35          # algorithmic FP64 operations of one scatter ev
 FP64_VECTOR_PEAK_TFLOPS = 78.6   # MI355X: 256 CU x 128 FLOP/clk x 2.4 GHz
 
 
-def cpu_baseline(cfg, n_cpu, seconds_cap=30.0):
-    """NumPy restatement of RunPhotons over the same tau list with n_cpu photons per atmosphere."""
+_CPU_CFG = None  # the workload, inherited by forked workers
+
+
+def _cpu_atmosphere(task):
+    """One atmosphere of the sweep through the NumPy restatement of RunPhotons; returns its scatter count."""
     from oracle import numpy_walk as nw
-    rs = np.random.RandomState(12345)
-    w = np.clip(np.nan_to_num(cfg["pdf"]), 0, 1)
-    cdf = np.cumsum(w)
-    events, t0, done = 0, time.perf_counter(), 0
-    for tau in cfg["tau_list"]:
-        idx = np.minimum(np.searchsorted(cdf, rs.rand(n_cpu) * cdf[-1], side="right"), len(cdf) - 1)
-        r = nw.run_photons(tau, cfg["wl"][idx], cfg["g"][idx], cfg["albedo"][idx], cfg["scale"][idx], np.ones(n_cpu),
-                           boundary=cfg["boundary"], scatter=cfg["scatter"], order=cfg["order"],
-                           stream=nw.GlobalStream(rs), h=cfg["h"])
-        events += r["scatter_count"]
-        done += 1
-        if time.perf_counter() - t0 > seconds_cap:
-            break
+    k, n_cpu = task
+    cfg = _CPU_CFG
+    rs = np.random.RandomState(12345 + k)
+    cdf = np.cumsum(np.clip(np.nan_to_num(cfg["pdf"]), 0, 1))
+    idx = np.minimum(np.searchsorted(cdf, rs.rand(n_cpu) * cdf[-1], side="right"), len(cdf) - 1)
+    r = nw.run_photons(cfg["tau_list"][k], cfg["wl"][idx], cfg["g"][idx], cfg["albedo"][idx], cfg["scale"][idx],
+                       np.ones(n_cpu), boundary=cfg["boundary"], scatter=cfg["scatter"], order=cfg["order"],
+                       stream=nw.GlobalStream(rs), h=cfg["h"])
+    return int(r["scatter_count"])
+
+
+def cpu_baseline(cfg, n_cpu, procs=1, seconds_cap=30.0):
+    """NumPy restatement of RunPhotons over the same tau list with n_cpu photons per atmosphere, on `procs`
+    host processes (atmospheres dealt out one at a time, thickest first so the cap cuts the cheap end)."""
+    global _CPU_CFG
+    _CPU_CFG = cfg
+    n_atm = len(cfg["tau_list"])
+    tasks = [(k, n_cpu) for k in range(n_atm)] if procs == 1 else [(k, n_cpu) for k in reversed(range(n_atm))]
+    events, done, t0 = 0, 0, time.perf_counter()
+    if procs == 1:
+        for t in tasks:
+            events += _cpu_atmosphere(t)
+            done += 1
+            if time.perf_counter() - t0 > seconds_cap:
+                break
+    else:
+        import multiprocessing as mp
+        with mp.get_context("fork").Pool(procs) as pool:  # forked before anything touches the GPU
+            for ev in pool.imap_unordered(_cpu_atmosphere, tasks):
+                events += ev
+                done += 1
+                if time.perf_counter() - t0 > seconds_cap:
+                    pool.terminate()
+                    break
     dt = time.perf_counter() - t0
-    return dict(value=events / dt, unit="scatter events/s", cores=1, kind="port",
-                sample=f"{n_cpu} photons/atmosphere x {done} of {len(cfg['tau_list'])} atmospheres of the same sweep "
-                       f"({events} events in {dt:.1f} s, oracle/numpy_walk.py, 1 process)")
+    return dict(value=events / dt, unit="scatter events/s", cores=procs, kind="port",
+                sample=f"{n_cpu} photons/atmosphere x {done} of {n_atm} atmospheres of the same sweep "
+                       f"({events} events in {dt:.1f} s, oracle/numpy_walk.py, {procs} process(es))")
 
 
 def measured_traffic(workload, per_gpu):
@@ -80,17 +104,31 @@ def main():
     ap.add_argument("--photons", type=int, default=0, help="photons per atmosphere per GPU (0 = the workload's own)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--cpu-photons", type=int, default=1000000)
+    ap.add_argument("--cpu-procs", type=int, default=0, help="processes of the all-cores CPU baseline (0 = min(16, cores))")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo stages the tallies through host memory; for rehearsing N > 1 on a box with fewer GPUs than ranks")
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
-
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+
+    rt = importlib.import_module("radiative-transfer_amd")
+    workloads = importlib.import_module("radiative-transfer_amd.workloads")
+    cfg = workloads.WORKLOADS[args.workload]()
+
+    # CPU baselines first: the worker processes are forked while this process has not touched the GPU
+    cpu = {}
+    if world == 1 and not args.no_cpu:
+        cpu["cpu_baseline"] = cpu_baseline(cfg, args.cpu_photons, 1)
+        procs = args.cpu_procs or min(16, len(os.sched_getaffinity(0)))
+        if procs > 1:
+            cpu["cpu_baseline_all_cores"] = cpu_baseline(cfg, args.cpu_photons, procs)
+
+    import torch
+    import torch.distributed as dist
+
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N ...")
@@ -109,10 +147,7 @@ def main():
         else:
             dist.init_process_group("gloo")
 
-    rt = importlib.import_module("radiative-transfer_amd")
-    workloads = importlib.import_module("radiative-transfer_amd.workloads")
     A = rt._abi
-    cfg = workloads.WORKLOADS[args.workload]()
     per_gpu = args.photons or cfg["n_photons"]
     n_slabs = 8
     total_photons = per_gpu * world if args.scaling == "weak" else per_gpu
@@ -192,8 +227,7 @@ def main():
                          "kernel": "walk_kernel", "kernel_avg_ms": kernel_ms, "kernel_launches": launches,
                          "flop_per_event": FP64_OPS_PER_EVENT},
         }
-        if world == 1 and not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_photons)
+        out.update(cpu)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -212,9 +212,11 @@ int rt_build_grain_tables(rt_ctx* ctx, const rt_grain_set* gs, double density, d
                           int32_t average_all_sizes, int32_t n_wl, const double* wl, const double* sed,
                           rt_grain_tables* out);
 
-/* Test hook (no reference counterpart): applies the kernels' own fp64 ln(u), cos(2*pi*u) and sqrt(u) to n host
- * values u in [0,1) so that their accuracy can be checked against a host math library. */
-int rt_selftest_math(rt_ctx* ctx, int64_t n, const double* u, double* out_log, double* out_cos, double* out_sqrt);
+/* Test hook (no reference counterpart): applies the kernels' own fp64 ln(u), cos(2*pi*u), sqrt(u) and
+ * division ((1 - u*u) / (2*u)) to n host values u in [0,1) so that they can be checked against a host
+ * math library. */
+int rt_selftest_math(rt_ctx* ctx, int64_t n, const double* u, double* out_log, double* out_cos, double* out_sqrt,
+                     double* out_div);
 
 /* Average kernel time (ms) and launch count of the walk kernel since the last call with reset != 0,
  * measured with HIP events on the stream the kernel ran on. */

@@ -93,7 +93,7 @@ def load_library(path=None):
                               c_double_p, c_double_p, c_double_p, C.POINTER(RtTallies), C.POINTER(RtPhotonTrace)]
     lib.rt_build_grain_tables.argtypes = [vp, C.POINTER(RtGrainSet), C.c_double, C.c_double, C.c_double, C.c_int32,
                                           C.c_int32, c_double_p, c_double_p, C.POINTER(RtGrainTables)]
-    lib.rt_selftest_math.argtypes = [vp, C.c_int64, c_double_p, c_double_p, c_double_p, c_double_p]
+    lib.rt_selftest_math.argtypes = [vp, C.c_int64, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p]
     lib.rt_kernel_time.argtypes = [vp, c_double_p, C.POINTER(C.c_int64), C.c_int]
     for name in EXPORTS:
         getattr(lib, name)  # AttributeError if an entry point is missing

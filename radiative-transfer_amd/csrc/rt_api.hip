@@ -653,18 +653,21 @@ int rt_build_grain_tables(rt_ctx* ctx, const rt_grain_set* gs, double density, d
     return RT_OK;
 }
 
-int rt_selftest_math(rt_ctx* ctx, int64_t n, const double* u, double* out_log, double* out_cos, double* out_sqrt) {
+int rt_selftest_math(rt_ctx* ctx, int64_t n, const double* u, double* out_log, double* out_cos, double* out_sqrt,
+                     double* out_div) {
     if (!ctx) return fail(RT_ERR_INVALID, "ctx is NULL");
-    if (n < 0 || (n > 0 && (!u || !out_log || !out_cos || !out_sqrt))) return fail(RT_ERR_INVALID, "bad argument");
+    if (n < 0 || (n > 0 && (!u || !out_log || !out_cos || !out_sqrt || !out_div))) return fail(RT_ERR_INVALID, "bad argument");
     if (n == 0) return RT_OK;
     RT_HIP(hipSetDevice(ctx->device));
     DevBuf<double> d;
-    hipError_t e = d.reserve(4 * (size_t)n);
+    hipError_t e = d.reserve(5 * (size_t)n);
     if (e == hipSuccess) e = hipMemcpyAsync(d.p, u, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = rt::launch_selftest_math(ctx->d_log_table.p, (long long)n, d.p, d.p + n, d.p + 2 * n, d.p + 3 * n, ctx->stream);
+    if (e == hipSuccess) e = rt::launch_selftest_math(ctx->d_log_table.p, (long long)n, d.p, d.p + n, d.p + 2 * n, d.p + 3 * n, d.p + 4 * n,
+                                                      ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(out_log, d.p + n, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(out_cos, d.p + 2 * n, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(out_sqrt, d.p + 3 * n, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out_div, d.p + 4 * n, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     d.release();
     if (e != hipSuccess) return fail(RT_ERR_DEVICE, "selftest failed: %s", hipGetErrorString(e));

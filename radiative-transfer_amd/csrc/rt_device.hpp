@@ -354,12 +354,12 @@ __device__ __forceinline__ int scatter(const Cfg& cfg, Photon& ph, Src& src, dou
         }
         if (!ok) return RT_FATE_GUARD;
     } else {
-        const double s = 2.0 * u_s - 1.0;
+        const double s = fma(2.0, u_s, -1.0);  // 2*u is exact, so this is (2*u) - 1 in one operation
         if (iso) {
             mu_prime = s;
             direct = true;
         } else {
-            const double q = ph.omg2 / (1.0 + ph.g * s);
+            const double q = FAST ? div_unit(ph.omg2, 1.0 + ph.g * s) : ph.omg2 / (1.0 + ph.g * s);
             mu_prime = ph.inv2g * (ph.opg2 - q * q);
         }
     }

@@ -400,7 +400,7 @@ __global__ __launch_bounds__(kWalkBlock) void replay_kernel(const Cfg cfg, const
 // The kernels' own ln() and cos(2 pi u) applied element-wise (test hook).
 __global__ void selftest_math_kernel(const LogTableEntry* __restrict__ table, long long n, const double* __restrict__ u,
                                      double* __restrict__ out_log, double* __restrict__ out_cos,
-                                     double* __restrict__ out_sqrt) {
+                                     double* __restrict__ out_sqrt, double* __restrict__ out_div) {
     __shared__ LogTableEntry lds_table[kLogTableEntries];
     for (int k = threadIdx.x; k < kLogTableEntries; k += blockDim.x) lds_table[k] = table[k];
     __syncthreads();
@@ -409,6 +409,7 @@ __global__ void selftest_math_kernel(const LogTableEntry* __restrict__ table, lo
         out_log[i] = log_unit(u[i], lds_table);
         out_cos[i] = cos_2pi(u[i]);
         out_sqrt[i] = sqrt_unit(u[i]);
+        out_div[i] = div_unit(1.0 - u[i] * u[i], 2.0 * u[i]);
     }
 }
 
@@ -500,8 +501,8 @@ hipError_t launch_grain_integrals(const GrainSetDev& gs, int n_wl, const double*
 }
 
 hipError_t launch_selftest_math(const LogTableEntry* d_table, long long n, const double* d_u, double* d_log,
-                                double* d_cos, double* d_sqrt, hipStream_t stream) {
-    selftest_math_kernel<<<(unsigned int)((n + 255) / 256), 256, 0, stream>>>(d_table, n, d_u, d_log, d_cos, d_sqrt);
+                                double* d_cos, double* d_sqrt, double* d_div, hipStream_t stream) {
+    selftest_math_kernel<<<(unsigned int)((n + 255) / 256), 256, 0, stream>>>(d_table, n, d_u, d_log, d_cos, d_sqrt, d_div);
     return hipGetLastError();
 }
 

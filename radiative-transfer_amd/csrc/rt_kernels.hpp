@@ -48,7 +48,7 @@ hipError_t launch_replay(const Cfg& cfg, double tau, long long n, int max_draws,
                          hipStream_t stream);
 
 hipError_t launch_selftest_math(const LogTableEntry* d_table, long long n, const double* d_u, double* d_log,
-                                double* d_cos, double* d_sqrt, hipStream_t stream);
+                                double* d_cos, double* d_sqrt, double* d_div, hipStream_t stream);
 
 }  // namespace rt
 

@@ -100,4 +100,25 @@ __device__ __forceinline__ double sqrt_unit(double x) {
 #endif
 }
 
+// ---------------------------------------------------------------------------
+// n / d for normal operands whose quotient needs no rescaling (HGScatter: n = 1 - g^2 in (0, 1],
+// d = 1 + g*s in (0, 2)): reciprocal seed, two Newton steps, quotient and one residual correction --
+// the sequence of the general fp64 division without its range scaling and special-case fix-up.
+// d = 0 gives NaN (the general division gives inf or NaN there).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double div_unit(double n, double d) {
+#ifdef RT_DIV_GENERAL
+    return n / d;
+#else
+    double r = __builtin_amdgcn_rcp(d);
+    double e = fma(-d, r, 1.0);
+    r = fma(r, e, r);
+    e = fma(-d, r, 1.0);
+    r = fma(r, e, r);
+    const double q = n * r;
+    const double res = fma(-d, q, n);
+    return fma(res, r, q);
+#endif
+}
+
 }  // namespace rt

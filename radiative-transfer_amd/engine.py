@@ -190,11 +190,11 @@ class Engine:
         return out
 
     def selftest_math(self, u):
-        """The device's ln(u), cos(2 pi u) and sqrt(u) for u in [0,1) (test hook)."""
+        """The device's ln(u), cos(2 pi u), sqrt(u) and (1 - u*u) / (2*u) for u in [0,1) (test hook)."""
         u = np.ascontiguousarray(u, dtype=np.float64)
-        out_log, out_cos, out_sqrt = np.empty_like(u), np.empty_like(u), np.empty_like(u)
-        self._check(self._lib.rt_selftest_math(self._ctx, len(u), _dp(u), _dp(out_log), _dp(out_cos), _dp(out_sqrt)))
-        return out_log, out_cos, out_sqrt
+        outs = [np.empty_like(u) for _ in range(4)]
+        self._check(self._lib.rt_selftest_math(self._ctx, len(u), _dp(u), *[_dp(o) for o in outs]))
+        return tuple(outs)
 
     def kernel_time(self, reset=False):
         ms, n = C.c_double(), C.c_int64()

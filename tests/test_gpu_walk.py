@@ -130,7 +130,7 @@ def test_device_math_accuracy(engine):
                         1 - 2.0 ** -rng.integers(1, 53, 2000), [2.0 ** -53, 0.25, 0.5, 0.75, 1 - 2.0 ** -53, 0.125]])
     u = np.floor(u * 2.0 ** 53) / 2.0 ** 53
     u = u[u > 0]
-    got_log, got_cos, got_sqrt = engine.selftest_math(u)
+    got_log, got_cos, got_sqrt, got_div = engine.selftest_math(u)
     ul = u.astype(np.longdouble)
     want_log = np.log(ul)
     err = np.abs(got_log.astype(np.longdouble) - want_log)
@@ -143,5 +143,7 @@ def test_device_math_accuracy(engine):
     assert np.array_equal(got_sqrt, np.sqrt(u))
     tiny = np.concatenate([2.0 ** -rng.integers(53, 107, 5000) * (1 + rng.random(5000)), [2.0 ** -106, 1.0, 4.0]])
     assert np.array_equal(engine.selftest_math(tiny)[2], np.sqrt(tiny))
-    lz, _, sz = engine.selftest_math(np.array([0.0]))
+    # ... and so is the division of HGScatter's operand ranges
+    assert np.array_equal(got_div, (1.0 - u * u) / (2.0 * u))
+    lz, _, sz, _ = engine.selftest_math(np.array([0.0]))
     assert np.isneginf(lz[0]) and sz[0] == 0.0
