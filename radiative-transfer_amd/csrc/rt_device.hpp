@@ -365,7 +365,11 @@ __device__ __forceinline__ int scatter(const Cfg& cfg, Photon& ph, Src& src, dou
     }
     // RotateIntoLabFrame
     double mu_new;
-    if (direct || mu_old == 1.0) {
+    if (FAST) {
+        // The mu == +-1 branches of the reference (MC code.py:605-612) give what the general formula gives
+        // there: 1 - mu^2 is exactly 0, so the first term is -(+-0) and the sum is mu' or -mu' exactly.
+        mu_new = -sqrt_unit((1.0 - mu_old * mu_old) * (1.0 - mu_prime * mu_prime)) * cos_2pi(u_phi) + mu_old * mu_prime;
+    } else if (direct || mu_old == 1.0) {
         mu_new = mu_prime;
     } else if (mu_old == -1.0) {
         mu_new = -mu_prime;

@@ -135,8 +135,9 @@ def test_device_math_accuracy(engine):
     want_log = np.log(ul)
     err = np.abs(got_log.astype(np.longdouble) - want_log)
     assert float(np.max(err / np.maximum(np.abs(want_log), 1.0))) < 4e-16  # absolute below |ln| = 1, relative above
-    want_cos = np.cos(2 * np.pi * ul)  # exact angle, not the rounded product 2*pi*u
-    assert float(np.max(np.abs(got_cos.astype(np.longdouble) - want_cos))) < 3e-16
+    pi_ld = np.longdouble("3.14159265358979323846264338327950288")
+    want_cos = np.cos(2 * pi_ld * ul)  # exact angle, not the rounded product 2*pi*u
+    assert float(np.max(np.abs(got_cos.astype(np.longdouble) - want_cos))) < 3.5e-16
     # and against what the reference computes: np.cos(2*np.pi*u) with the product rounded to double
     assert float(np.max(np.abs(got_cos - np.cos(2 * np.pi * u)))) < 1.2e-15
     # the square root is the correctly rounded one on its whole domain, products of two (1 - mu^2) included
