@@ -117,6 +117,24 @@ struct Acc {
 #pragma unroll
         for (int k = 0; k < RT_NCNT; ++k) c[k] = 0u;
     }
+    __device__ __forceinline__ void count(int k) { c[k]++; }
+    __device__ __forceinline__ void count_if(int k, bool p) { c[k] += p; }
+};
+
+// Tallies of the fast kernel: the integer tallies other than the boundary hits are counted per WAVE by the
+// kernel itself (population counts of lane masks, scalar registers), so the per-lane hooks do nothing.
+struct AccWave {
+    double s[RT_NSUM];
+    uint32_t hits;
+    __device__ __forceinline__ void clear() {
+#pragma unroll
+        for (int k = 0; k < RT_NSUM; ++k) s[k] = 0.0;
+        hits = 0u;
+    }
+    __device__ __forceinline__ void count(int k) {
+        if (k == RT_CNT_BOUNDARY_HITS) hits++;
+    }
+    __device__ __forceinline__ void count_if(int, bool) {}
 };
 
 // Wave-private histograms in LDS (pointers are null when the tally is off) and the
@@ -258,16 +276,16 @@ __device__ __forceinline__ double draine_pdf(double g, double alpha, double m) {
 // FAST fixes (RT_ORDER_MC, reflect, hg, no depth bins, abs_only off) at compile time; the
 // generic form reads cfg.  `reemit` is called when a photon is re-emitted at the lower boundary.
 // ---------------------------------------------------------------------------
-template <bool FAST, class Reemit>
+template <bool FAST, class Reemit, class AccT>
 __device__ __forceinline__ int fly(const Cfg& cfg, Photon& ph, double u_step, double u_abs, int avail, bool bounded,
-                                   Acc& acc, const Hist& hist, Reemit&& reemit, int& n_used) {
+                                   AccT& acc, const Hist& hist, Reemit&& reemit, int& n_used) {
     const bool gray = FAST ? false : cfg.order == RT_ORDER_GRAY;
     const int boundary = FAST ? (int)RT_BOUNDARY_REFLECT : cfg.boundary;
     const bool depth = FAST ? false : cfg.n_depth_bins > 0;
 
     if (bounded && avail < 1) return RT_FATE_GUARD;
     ph.iter++;
-    acc.c[RT_CNT_FLIGHTS]++;
+    acc.count(RT_CNT_FLIGHTS);
     n_used += 1;
 
     // TakeStep
@@ -279,7 +297,7 @@ __device__ __forceinline__ int fly(const Cfg& cfg, Photon& ph, double u_step, do
     }
     if (ph.z <= 0.0) {  // CheckBoundary
         const double pb = ph.mu * ph.wh;
-        acc.c[RT_CNT_BOUNDARY_HITS]++;
+        acc.count(RT_CNT_BOUNDARY_HITS);
         if (boundary == RT_BOUNDARY_REFLECT) {
             ph.b -= pb;
             ph.z = -ph.z;
@@ -289,7 +307,7 @@ __device__ __forceinline__ int fly(const Cfg& cfg, Photon& ph, double u_step, do
             return RT_FATE_BOUNDARY;
         } else {
             ph.b += pb;
-            acc.c[RT_CNT_REEMITTED]++;
+            acc.count(RT_CNT_REEMITTED);
             reemit(ph);
             acc.s[RT_SUM_REEMITTED] += ph.mu * ph.wh;
         }
@@ -321,9 +339,9 @@ __device__ __forceinline__ int fly(const Cfg& cfg, Photon& ph, double u_step, do
     return 0;
 }
 
-template <bool FAST, class Src>
+template <bool FAST, class Src, class AccT>
 __device__ __forceinline__ int scatter(const Cfg& cfg, Photon& ph, Src& src, double u_phi, double u_s, int avail2,
-                                       Acc& acc, const Hist& hist) {
+                                       AccT& acc, const Hist& hist) {
     const bool gray = FAST ? false : cfg.order == RT_ORDER_GRAY;
     const int law = FAST ? (int)RT_SCATTER_HG : cfg.scatter;
     const bool depth = FAST ? false : cfg.n_depth_bins > 0;
@@ -378,7 +396,7 @@ __device__ __forceinline__ int scatter(const Cfg& cfg, Photon& ph, Src& src, dou
     }
     ph.mu = mu_new;
     ph.n_scatter++;
-    acc.c[RT_CNT_SCATTER]++;
+    acc.count(RT_CNT_SCATTER);
     const double dp = (mu_old - mu_new) * ph.wh;
     acc.s[RT_SUM_DUST_MOMENTUM] += dp;
     if (depth) atomicAdd(&hist.depth_mom[depth_bin(cfg, ph)], dp);
@@ -402,13 +420,14 @@ __device__ __forceinline__ int flight(const Cfg& cfg, Photon& ph, Src& src, Acc&
 }
 
 // Bookkeeping when a photon's history ends.
-__device__ __forceinline__ void retire(const Cfg& cfg, const Photon& ph, int fate, Acc& acc, const Hist& hist) {
+template <class AccT>
+__device__ __forceinline__ void retire(const Cfg& cfg, const Photon& ph, int fate, AccT& acc, const Hist& hist) {
     const bool gray = cfg.order == RT_ORDER_GRAY;
-    acc.c[RT_CNT_ESCAPED] += fate == RT_FATE_ESCAPED;
-    acc.c[RT_CNT_ESCAPED_UNCOUNTED] += fate == RT_FATE_ESCAPED_UNCOUNTED;
-    acc.c[RT_CNT_ABSORBED] += fate == RT_FATE_ABSORBED;
-    acc.c[RT_CNT_BOUNDARY_ABSORBED] += fate == RT_FATE_BOUNDARY;
-    acc.c[RT_CNT_GUARD] += fate == RT_FATE_GUARD;
+    acc.count_if(RT_CNT_ESCAPED, fate == RT_FATE_ESCAPED);
+    acc.count_if(RT_CNT_ESCAPED_UNCOUNTED, fate == RT_FATE_ESCAPED_UNCOUNTED);
+    acc.count_if(RT_CNT_ABSORBED, fate == RT_FATE_ABSORBED);
+    acc.count_if(RT_CNT_BOUNDARY_ABSORBED, fate == RT_FATE_BOUNDARY);
+    acc.count_if(RT_CNT_GUARD, fate == RT_FATE_GUARD);
     acc.s[RT_SUM_ESCAPED] += ph.e1;
     acc.s[RT_SUM_BOUNDARY] += ph.b;
     const double t = ph.p0 - ph.e1 + ph.b;
@@ -423,14 +442,15 @@ __device__ __forceinline__ void retire(const Cfg& cfg, const Photon& ph, int fat
     }
 }
 
-__device__ __forceinline__ void start_photon(Photon& ph, Acc& acc) {
+template <class AccT>
+__device__ __forceinline__ void start_photon(Photon& ph, AccT& acc) {
     ph.p0 = ph.mu * ph.wh;
     ph.e1 = 0.0;
     ph.b = 0.0;
     ph.iter = 0u;
     ph.n_scatter = 0;
     acc.s[RT_SUM_INITIAL] += ph.p0;
-    acc.c[RT_CNT_PHOTONS]++;
+    acc.count(RT_CNT_PHOTONS);
 }
 
 }  // namespace rt

@@ -138,6 +138,25 @@ __device__ __forceinline__ void store_chunk(const Acc& acc, const WorkItem& it, 
     flush_hist(hist, lane, nmu, nd, it.atm, n_atm, d_mu_hist, d_depth);
 }
 
+// Same for the fast kernel: the integer tallies are already wave totals (wave-uniform values).
+__device__ __forceinline__ void store_chunk_wave(const AccWave& acc, const unsigned long long (&wc)[RT_NCNT],
+                                                 const WorkItem& it, const Hist& hist, int lane, int nmu,
+                                                 uint32_t n_atm, double* d_chunk_sums, unsigned long long* d_counts,
+                                                 unsigned long long* d_mu_hist, double* d_depth) {
+#pragma unroll
+    for (int k = 0; k < RT_NSUM; ++k) {
+        const double v = wave_sum(acc.s[k]);
+        if (lane == 0) d_chunk_sums[it.slot * RT_NSUM + k] = v;
+    }
+    const uint32_t hits = wave_sum_u32(acc.hits);
+#pragma unroll
+    for (int k = 0; k < RT_NCNT; ++k) {
+        const unsigned long long v = k == RT_CNT_BOUNDARY_HITS ? (unsigned long long)hits : wc[k];
+        if (lane == 0 && v) atomicAdd(&d_counts[(size_t)it.atm * RT_NCNT + k], v);
+    }
+    flush_hist(hist, lane, nmu, 0, it.atm, n_atm, d_mu_hist, d_depth);
+}
+
 // Generic persistent kernel: every boundary / scattering law / loop order, depth bins, re-emission.
 // Per iteration: refill dead lanes, then one full flight (fly + scatter) per live lane.
 __global__ __launch_bounds__(kWalkBlock) void walk_kernel(const Cfg cfg, const Sweep sw,
@@ -238,8 +257,9 @@ __global__ __launch_bounds__(kWalkBlock) void walk_fast_kernel(const Cfg cfg, co
     WorkItem it;
     while (pop_item(sw, d_next, lane, it)) {
         const double tau = it.tau;
-        Acc acc;
+        AccWave acc;
         acc.clear();
+        unsigned long long wc[RT_NCNT] = {};  // wave totals, the same value in every lane
         Photon ph = {};
         PhiloxSrc src = {};
         src.atm = it.atm;
@@ -266,6 +286,11 @@ __global__ __launch_bounds__(kWalkBlock) void walk_fast_kernel(const Cfg cfg, co
             }
             const bool active = alive || fresh;
             if (__ballot(active) == 0ull) break;
+            // integer tallies as population counts of lane masks, taken here where every lane of the wave arrives
+            wc[RT_CNT_PHOTONS] += (unsigned long long)__popcll(__builtin_amdgcn_ballot_w64(fresh));
+            wc[RT_CNT_SCATTER] += (unsigned long long)__popcll(__builtin_amdgcn_ballot_w64(alive));
+            int fate = 0;
+            bool flew = false;
             if (active) {
                 // ---- one Philox call: emission block for fresh lanes, scattering block otherwise ----
                 const uint32_t block = fresh ? kEmitBlock : src.blk;
@@ -295,8 +320,9 @@ __global__ __launch_bounds__(kWalkBlock) void walk_fast_kernel(const Cfg cfg, co
                     start_photon(ph, acc);
                     alive = true;
                 }
-                int fate = RT_FATE_GUARD;
+                fate = RT_FATE_GUARD;
                 if (!guard) {
+                    flew = true;
                     int n_used = 0;
                     fate = fly<true>(cfg, ph, u_step, u_abs, 2, false, acc, hist, no_reemit, n_used);
                 }
@@ -305,8 +331,15 @@ __global__ __launch_bounds__(kWalkBlock) void walk_fast_kernel(const Cfg cfg, co
                     alive = false;
                 }
             }
+            wc[RT_CNT_FLIGHTS] += (unsigned long long)__popcll(__builtin_amdgcn_ballot_w64(flew));
+            wc[RT_CNT_ESCAPED] += (unsigned long long)__popcll(__builtin_amdgcn_ballot_w64(fate == RT_FATE_ESCAPED));
+            wc[RT_CNT_ESCAPED_UNCOUNTED] +=
+                (unsigned long long)__popcll(__builtin_amdgcn_ballot_w64(fate == RT_FATE_ESCAPED_UNCOUNTED));
+            wc[RT_CNT_GUARD] += (unsigned long long)__popcll(__builtin_amdgcn_ballot_w64(fate == RT_FATE_GUARD));
         }
-        store_chunk(acc, it, hist, lane, nmu, 0, sw.n_atm, d_chunk_sums, d_counts, d_mu_hist, d_depth);
+        // every photon started in this chunk also ended in it
+        wc[RT_CNT_ABSORBED] = wc[RT_CNT_PHOTONS] - wc[RT_CNT_ESCAPED] - wc[RT_CNT_ESCAPED_UNCOUNTED] - wc[RT_CNT_GUARD];
+        store_chunk_wave(acc, wc, it, hist, lane, nmu, sw.n_atm, d_chunk_sums, d_counts, d_mu_hist, d_depth);
     }
 }
 
