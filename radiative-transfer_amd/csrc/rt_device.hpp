@@ -198,7 +198,7 @@ __device__ __forceinline__ int sample_index(const Cfg& cfg, double u) {
     if (cfg.mono_index >= 0) return cfg.mono_index;
     const double x = u * (double)cfg.n_wl;
     int i = (int)x;
-    i = i < cfg.n_wl ? i : cfg.n_wl - 1;  // u*n can round up to n for u = 1 - 2^-53
+    i = i < cfg.n_wl ? i : cfg.n_wl - 1;  // u*n can round up to n for u just below 1
     const double frac = x - (double)i;
 #ifdef RT_ABLATE_ALIAS
     return frac < 0.5 ? i : (i ^ 1);

@@ -1,7 +1,7 @@
 // rt_math.hpp -- fp64 elementary functions shaped for the walk kernel (gfx950).
 //
 // The two transcendental calls of a loop iteration have very restricted arguments:
-//   step  = -ln(xi)            xi = k / 2^53 in [0, 1)          (TakeStep, MC code.py:496)
+//   step  = -ln(xi)            xi = k / 2^52 in [0, 1)          (TakeStep, MC code.py:496)
 //   cos(phi), phi = 2*pi*xi    xi in [0, 1)                     (RotateIntoLabFrame, MC code.py:615)
 // so neither needs the general-purpose library routines (argument reduction for huge angles,
 // subnormal handling, ...).  Both functions below are accurate to a few 1e-16 ABSOLUTE; the parity
