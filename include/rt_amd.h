@@ -212,6 +212,67 @@ int rt_build_grain_tables(rt_ctx* ctx, const rt_grain_set* gs, double density, d
                           int32_t average_all_sizes, int32_t n_wl, const double* wl, const double* sed,
                           rt_grain_tables* out);
 
+/* ---- the consumer of the curve: shell velocities of many H II regions (the step after the walk) ---- */
+enum rt_shell_status {
+    RT_SHELL_REACHED_END = 0, /* integrated to r_end */
+    RT_SHELL_STALLED = 1,     /* v -> 0 before r_end; r_last is the stall radius */
+    RT_SHELL_ESCAPED = 2,     /* passed r_escape (the reference sets dv/dr = -inf there, MC code.py:951-953) */
+    RT_SHELL_STEP_LIMIT = 3   /* max_steps used up */
+};
+
+/* What ODEs reads besides the region (MC code.py:905-955): the curve MC_data (GetMC, :843-863), the
+ * luminosity of the population per age (L_ratio, :917) and the physical constants.  All pointers are host
+ * arrays; grids ascending. */
+typedef struct rt_shell_model {
+    int32_t aging;           /* stellar_aging */
+    int32_t static_momentum; /* MC code.py:119 */
+    int32_t n_tau, n_age, n_lage, pad_;
+    double G, c, sigma_sb, year_s; /* cgs; year_s = 31556952 (MC code.py:943) */
+    double h_hi_cm;                /* h_Hi * cm_pc */
+    double r_escape;               /* 10000 * cm_pc */
+    double time_slice;             /* log10 age used when aging == 0 */
+    double tau_cutoff;             /* GetMC's tau_cutoff; 0 = off */
+    double l_norm;                 /* summed luminosity at time_slice */
+    const double* mc_tau;          /* [n_tau]  MC_data.tau */
+    const double* mc_age;          /* [n_age]  the age columns of MC_data as numbers */
+    const double* mc_val;          /* [n_tau][n_age] */
+    const double* l_age;           /* [n_lage] ages of l_val / ratio_val */
+    const double* l_val;           /* [n_lage] summed luminosity per age (needed if aging) */
+    const double* ratio_val;       /* [n_lage] GetRatios' ratio_rp_lambda_rp per age (needed if tau_cutoff > 0) */
+} rt_shell_model;
+
+/* regionData of GetRegionVelocity (MC code.py:1438-1457), one entry per region, cgs units. */
+typedef struct rt_shell_regions {
+    int32_t n, pad_;
+    const double *m_g, *m_new, *m_old, *m_co_hi, *h_old, *h_g_i, *tau_i, *l_bol, *sigma_g;
+    const double* r_end; /* integrate from h_g_i to here (the reference: 100 * H_old, MC code.py:1459) */
+} rt_shell_regions;
+
+typedef struct rt_shell_control {
+    double v0, t0;               /* v_0 (cm/s), t_0 (yr): MC code.py:102-103 */
+    double rtol, atol_v, atol_t; /* local error control of the embedded pair */
+    double max_step;             /* cm; the reference uses cm_pc */
+    int32_t n_out;               /* samples per region at r0 + (k+1)/n_out (r_end - r0); 0 = none */
+    int32_t max_steps;
+} rt_shell_control;
+
+/* Host result arrays, [n] each; v_out / t_out are [n][n_out] (NaN beyond the last radius reached). */
+typedef struct rt_shell_result {
+    double *v_max, *r_vmax, *t_vmax; /* largest velocity and where / when */
+    double *r_last, *v_last, *t_last;
+    int32_t *status, *n_steps;
+    double *v_out, *t_out;
+} rt_shell_result;
+
+/* Replaces the per-region loop over GetRegionVelocity (MC code.py:1433-1472, spherical case). */
+int rt_shell_velocity(rt_ctx* ctx, const rt_shell_model* model, const rt_shell_regions* regions,
+                      const rt_shell_control* control, rt_shell_result* out);
+
+/* dv/dr and dt/dr of ODEs (MC code.py:905-955) at n points (region[i], r[i], v[i], t[i]). */
+int rt_shell_rhs(rt_ctx* ctx, const rt_shell_model* model, const rt_shell_regions* regions, int32_t n,
+                 const int32_t* region, const double* r, const double* v, const double* t, double* dvdr,
+                 double* dtdr);
+
 /* Test hook (no reference counterpart): applies the kernels' own fp64 ln(u), cos(2*pi*u), sqrt(u) and
  * division ((1 - u*u) / (2*u)) to n host values u in [0,1) so that they can be checked against a host
  * math library. */

@@ -1,0 +1,105 @@
+"""NumPy restatement of the reference's shell-velocity right-hand side and its integration.
+
+TEST INFRASTRUCTURE ONLY (oracle).  The product's integrator is the HIP kernel in
+radiative-transfer_amd/csrc/rt_shell.hip; nothing under radiative-transfer_amd/ imports this file.
+
+Restates, one scalar point at a time and with the reference's own expressions:
+    get_tau_IR   MC code.py:781-807
+    GetRatios    MC code.py:1130-1152   (ratio_rp_lambda_rp, always the np.interp branch: `time in
+                                          L_Edd_DF.time` tests the time MODULE and is never true)
+    GetMC        MC code.py:843-863
+    ODEs         MC code.py:905-955     (includeWholeGalaxy off)
+Pinned by tests/golden/shell.npz, which holds the reference's own outputs (oracle/make_golden_shell.py).
+Where the reference's interpn raises (points outside the curve's grid) this restatement clamps, as the
+device code does; the golden file has NaN there and the tests skip those points.
+"""
+import numpy as np
+from scipy import integrate
+
+CM_PC = 3.086 * 10 ** 18
+C_LIGHT = 2.99792458 * (10 ** 10)
+G_NEWTON = 6.67259 * (10 ** -8)
+SIGMA_SB = 5.67037441918442945397 * 10 ** -5
+
+
+class Model:
+    def __init__(self, z, aging=False, tau_cutoff=0.0, static_momentum=False, grain_mix=(0.5, 0.45, 0.05)):
+        """z: the arrays of tests/golden/shell.npz."""
+        self.mc_tau, self.mc_ages, self.mc_values = z["mc_tau"], z["mc_ages"], z["mc_values"]
+        self.l_ages, self.l_values = z["l_ages"], z["l_values"]
+        self.kappa_av = sum(f * z["kappa_av_RP_" + s] for f, s in zip(grain_mix, ("Sil", "Gra", "SiC")))
+        self.kappa_rp_ref = float(z["kappa_rp_ref"])
+        self.time_slice = float(z["time_slice"])
+        self.h_hi_cm = float(z["h_Hi"]) * CM_PC
+        self.aging, self.tau_cutoff, self.static_momentum = bool(aging), float(tau_cutoff), bool(static_momentum)
+        self.l_norm = float(self.l_values[np.where(self.l_ages == self.time_slice)[0][0]])
+
+
+class Region:
+    def __init__(self, z, i):
+        g = lambda k: float(z["reg_" + k][i])
+        self.M_g, self.M_new, self.M_old, self.M_CO_Hi = g("Mass_g"), g("Mass_new"), g("Mass_old"), g("Mass_CO_Hi")
+        self.H_old, self.tau_i, self.L_Bol, self.Sigma_g = g("H_old"), g("tau"), g("L_Bol"), g("Sigma_g")
+        self.h_g_i = float(z["h_g"]) * CM_PC
+
+
+def get_tau_ir(r, l_bol, sigma_g):
+    t_eff = (l_bol / (4 * np.pi * r ** 2 * SIGMA_SB)) ** 0.25
+    tau_r = 2.4 * 10 ** -4 * t_eff ** 2 * sigma_g
+    if tau_r > 1:
+        temp = (3 / 4 * (tau_r + 2 / 3) * t_eff ** 4) ** 0.25
+        return 2.4 * 10 ** -4 * temp ** 2 * sigma_g
+    return tau_r
+
+
+def get_mc(m, tau, new_time):
+    vals = m.mc_values
+    if m.tau_cutoff > 0:
+        ratio = np.interp(new_time, m.l_ages, m.kappa_av) / m.kappa_rp_ref
+        thin = m.mc_tau * ratio < m.tau_cutoff
+        vals = np.where(thin[:, None], (1 - np.exp(-m.mc_tau * ratio))[:, None], vals)
+    hit = np.where(m.mc_ages == new_time)[0]
+    if len(hit):
+        return float(np.interp(tau, m.mc_tau, vals[:, hit[0]]))
+    # scipy's linear interpn on the (tau, age) grid, clamped
+    tq = min(max(tau, m.mc_tau[0]), m.mc_tau[-1])
+    aq = min(max(new_time, m.mc_ages[0]), m.mc_ages[-1])
+    i = int(np.clip(np.searchsorted(m.mc_tau, tq, side="right") - 1, 0, len(m.mc_tau) - 2))
+    k = int(np.clip(np.searchsorted(m.mc_ages, aq, side="right") - 1, 0, len(m.mc_ages) - 2))
+    y0 = (tq - m.mc_tau[i]) / (m.mc_tau[i + 1] - m.mc_tau[i])
+    y1 = (aq - m.mc_ages[k]) / (m.mc_ages[k + 1] - m.mc_ages[k])
+    return float((1 - y0) * (1 - y1) * vals[i, k] + (1 - y0) * y1 * vals[i, k + 1] + y0 * (1 - y1) * vals[i + 1, k]
+                 + y0 * y1 * vals[i + 1, k + 1])
+
+
+def rhs(r, X, m, q):
+    v, t = X
+    new_time = np.log10(t)
+    l_bol = q.L_Bol
+    tau_new = (q.h_g_i / r) ** 2 * q.tau_i
+    log_age = m.time_slice
+    if m.aging:
+        l_bol = l_bol * (np.interp(new_time, m.l_ages, m.l_values) / m.l_norm)
+        log_age = new_time
+    momentum = get_mc(m, q.tau_i if m.static_momentum else tau_new, log_age) + get_tau_ir(r, l_bol, (q.h_g_i / r) ** 2 * q.Sigma_g)
+    mass = (q.M_g + q.M_CO_Hi * (min(r, m.h_hi_cm) / q.h_g_i) ** 3 + q.M_new + q.M_old * (min(r, q.H_old) / q.h_g_i) ** 3)
+    dvdr = (-G_NEWTON * mass / r ** 2 + momentum * l_bol / (C_LIGHT * q.M_g)) / v
+    dtdr = 1 / (v * 31556952)
+    if r > 10000 * CM_PC:
+        dvdr = -np.inf
+    return dvdr, dtdr
+
+
+def integrate_region(m, q, r_end, v_0, t_0, n_out, rtol=1e-10, max_step=CM_PC):
+    """v and t at r0 + (k+1)/n_out (r_end - r0); NaN beyond what could be integrated.  Also the last radius."""
+    r0 = q.h_g_i
+    grid = r0 + (np.arange(n_out) + 1.0) / n_out * (r_end - r0)
+    sol = integrate.solve_ivp(rhs, [r0, r_end], [v_0, t_0], args=(m, q), method="DOP853", rtol=rtol, atol=[1e-7, 1e-7],
+                              max_step=max_step, dense_output=True)
+    v = np.full(n_out, np.nan)
+    t = np.full(n_out, np.nan)
+    ok = grid <= r0 + 0.98 * (sol.t[-1] - r0) if sol.status != 0 else np.ones(n_out, bool)
+    if ok.any():
+        y = sol.sol(grid[ok])
+        v[ok], t[ok] = y[0], y[1]
+    return v, t, sol.t[-1], sol.status, float(np.max(sol.y[0]))

@@ -59,13 +59,41 @@ class RtGrainTables(C.Structure):
                 ("lum", C.c_double)]
 
 
+class RtShellModel(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("aging", "static_momentum", "n_tau", "n_age", "n_lage", "pad_")] \
+             + [(n, C.c_double) for n in ("G", "c", "sigma_sb", "year_s", "h_hi_cm", "r_escape", "time_slice",
+                                          "tau_cutoff", "l_norm")] \
+             + [(n, c_double_p) for n in ("mc_tau", "mc_age", "mc_val", "l_age", "l_val", "ratio_val")]
+
+
+SHELL_REGION_FIELDS = ("m_g", "m_new", "m_old", "m_co_hi", "h_old", "h_g_i", "tau_i", "l_bol", "sigma_g", "r_end")
+
+
+class RtShellRegions(C.Structure):
+    _fields_ = [("n", C.c_int32), ("pad_", C.c_int32)] + [(n, c_double_p) for n in SHELL_REGION_FIELDS]
+
+
+class RtShellControl(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("v0", "t0", "rtol", "atol_v", "atol_t", "max_step")] \
+             + [("n_out", C.c_int32), ("max_steps", C.c_int32)]
+
+
+class RtShellResult(C.Structure):
+    _fields_ = [(n, c_double_p) for n in ("v_max", "r_vmax", "t_vmax", "r_last", "v_last", "t_last")] \
+             + [("status", C.POINTER(C.c_int32)), ("n_steps", C.POINTER(C.c_int32)), ("v_out", c_double_p), ("t_out", c_double_p)]
+
+
+SHELL_REACHED_END, SHELL_STALLED, SHELL_ESCAPED, SHELL_STEP_LIMIT = 0, 1, 2, 3
+
+
 class RtPhotonTrace(C.Structure):
     _fields_ = [("final_z", C.c_double), ("final_mu", C.c_double), ("fate", C.c_int32),
                 ("n_scatter", C.c_int32), ("n_draws", C.c_int32), ("pad_", C.c_int32)]
 
 
 EXPORTS = ["rt_abi_version", "rt_last_error", "rt_create", "rt_destroy", "rt_device_info", "rt_set_tables",
-           "rt_run", "rt_run_device", "rt_replay", "rt_kernel_time", "rt_selftest_math", "rt_build_grain_tables"]
+           "rt_run", "rt_run_device", "rt_replay", "rt_kernel_time", "rt_selftest_math", "rt_build_grain_tables",
+           "rt_shell_velocity", "rt_shell_rhs"]
 
 _lib = None
 
@@ -93,6 +121,11 @@ def load_library(path=None):
                               c_double_p, c_double_p, c_double_p, C.POINTER(RtTallies), C.POINTER(RtPhotonTrace)]
     lib.rt_build_grain_tables.argtypes = [vp, C.POINTER(RtGrainSet), C.c_double, C.c_double, C.c_double, C.c_int32,
                                           C.c_int32, c_double_p, c_double_p, C.POINTER(RtGrainTables)]
+    i32p = C.POINTER(C.c_int32)
+    lib.rt_shell_velocity.argtypes = [vp, C.POINTER(RtShellModel), C.POINTER(RtShellRegions), C.POINTER(RtShellControl),
+                                      C.POINTER(RtShellResult)]
+    lib.rt_shell_rhs.argtypes = [vp, C.POINTER(RtShellModel), C.POINTER(RtShellRegions), C.c_int32, i32p, c_double_p,
+                                 c_double_p, c_double_p, c_double_p, c_double_p]
     lib.rt_selftest_math.argtypes = [vp, C.c_int64, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p]
     lib.rt_kernel_time.argtypes = [vp, c_double_p, C.POINTER(C.c_int64), C.c_int]
     for name in EXPORTS:

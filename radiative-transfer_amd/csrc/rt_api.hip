@@ -607,11 +607,7 @@ int rt_build_grain_tables(rt_ctx* ctx, const rt_grain_set* gs, double density, d
     dev.q_sca = d_cols.p + 2 * rows;
     dev.g = d_cols.p + 3 * rows;
     dev.n_sizes = ns;
-    EventPair* ev = nullptr;
-    if (e == hipSuccess) e = next_events(ctx, &ev);
-    if (e == hipSuccess) e = hipEventRecord(ev->a, s);
     if (e == hipSuccess) e = rt::launch_grain_integrals(dev, n_wl, d_wl.p, lo_k, hi_k, lo_a, hi_a, d_out.p, s);
-    if (e == hipSuccess) e = hipEventRecord(ev->b, s);
     std::vector<double> host(6 * (size_t)n_wl);
     if (e == hipSuccess) e = hipMemcpyAsync(host.data(), d_out.p, sizeof(double) * host.size(), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
@@ -650,6 +646,172 @@ int rt_build_grain_tables(rt_ctx* ctx, const rt_grain_set* gs, double density, d
         if (out->g_av) out->g_av[j] = host[4 * n + j] / norm;
         if (out->q_ext) out->q_ext[j] = host[5 * n + j] / norm;
     }
+    return RT_OK;
+}
+
+// ---- shell velocity ODE ----
+namespace {
+
+// Host arrays of the model and the regions packed into one device buffer; fills device-pointer copies.
+struct ShellUpload {
+    DevBuf<double> buf;
+    std::vector<double> host;
+    std::vector<size_t> off;
+    size_t add(const double* p, size_t n) {
+        const size_t o = host.size();
+        if (p && n) host.insert(host.end(), p, p + n);
+        off.push_back(o);
+        return o;
+    }
+};
+
+int check_shell_model(const rt_shell_model* m) {
+    if (!m) return fail(RT_ERR_INVALID, "model is NULL");
+    if (m->n_tau < 2 || m->n_age < 1 || !m->mc_tau || !m->mc_age || !m->mc_val)
+        return fail(RT_ERR_INVALID, "the curve needs at least 2 optical depths and 1 age");
+    for (int i = 1; i < m->n_tau; ++i)
+        if (!(m->mc_tau[i] > m->mc_tau[i - 1])) return fail(RT_ERR_INVALID, "mc_tau must be strictly ascending");
+    for (int i = 1; i < m->n_age; ++i)
+        if (!(m->mc_age[i] > m->mc_age[i - 1])) return fail(RT_ERR_INVALID, "mc_age must be strictly ascending");
+    if (m->aging && (m->n_lage < 2 || !m->l_age || !m->l_val || !(m->l_norm > 0.0)))
+        return fail(RT_ERR_INVALID, "aging needs the luminosity per age (l_age, l_val, l_norm)");
+    if (m->tau_cutoff > 0.0 && (m->n_lage < 1 || !m->l_age || !m->ratio_val))
+        return fail(RT_ERR_INVALID, "tau_cutoff > 0 needs ratio_val per age");
+    if (m->aging && m->n_age < 2) return fail(RT_ERR_INVALID, "aging needs a curve with at least 2 ages");
+    return RT_OK;
+}
+
+int check_shell_regions(const rt_shell_regions* rg) {
+    if (!rg) return fail(RT_ERR_INVALID, "regions is NULL");
+    if (rg->n < 0) return fail(RT_ERR_INVALID, "negative region count");
+    if (rg->n > 0 && (!rg->m_g || !rg->m_new || !rg->m_old || !rg->m_co_hi || !rg->h_old || !rg->h_g_i || !rg->tau_i ||
+                      !rg->l_bol || !rg->sigma_g || !rg->r_end))
+        return fail(RT_ERR_INVALID, "a region array is NULL");
+    for (int i = 0; i < rg->n; ++i) {
+        if (!(rg->h_g_i[i] > 0.0) || !(rg->m_g[i] > 0.0)) return fail(RT_ERR_INVALID, "region %d: h_g_i and m_g must be positive", i);
+        if (!(rg->r_end[i] >= rg->h_g_i[i])) return fail(RT_ERR_INVALID, "region %d: r_end below the starting radius", i);
+    }
+    return RT_OK;
+}
+
+// Packs model + regions, uploads, and returns device-pointer views.
+hipError_t upload_shell(rt_ctx* ctx, const rt_shell_model* m, const rt_shell_regions* rg, ShellUpload& up,
+                        rt::ShellModel& dm, rt::ShellRegions& dr) {
+    const size_t n = (size_t)rg->n;
+    const size_t o_tau = up.add(m->mc_tau, (size_t)m->n_tau), o_age = up.add(m->mc_age, (size_t)m->n_age);
+    const size_t o_val = up.add(m->mc_val, (size_t)m->n_tau * (size_t)m->n_age);
+    const size_t nl = (m->aging || m->tau_cutoff > 0.0) ? (size_t)m->n_lage : 0;
+    const size_t o_la = up.add(m->l_age, nl), o_lv = up.add(m->aging ? m->l_val : nullptr, m->aging ? nl : 0);
+    const size_t o_rv = up.add(m->tau_cutoff > 0.0 ? m->ratio_val : nullptr, m->tau_cutoff > 0.0 ? nl : 0);
+    const double* cols[10] = {rg->m_g, rg->m_new, rg->m_old, rg->m_co_hi, rg->h_old, rg->h_g_i, rg->tau_i, rg->l_bol,
+                              rg->sigma_g, rg->r_end};
+    size_t o_col[10];
+    for (int k = 0; k < 10; ++k) o_col[k] = up.add(cols[k], n);
+    if (up.host.empty()) up.host.push_back(0.0);
+    hipError_t e = up.buf.reserve(up.host.size());
+    if (e != hipSuccess) return e;
+    e = hipMemcpyAsync(up.buf.p, up.host.data(), sizeof(double) * up.host.size(), hipMemcpyHostToDevice, ctx->stream);
+    if (e != hipSuccess) return e;
+    dm = *m;
+    dm.mc_tau = up.buf.p + o_tau;
+    dm.mc_age = up.buf.p + o_age;
+    dm.mc_val = up.buf.p + o_val;
+    dm.l_age = up.buf.p + o_la;
+    dm.l_val = up.buf.p + o_lv;
+    dm.ratio_val = up.buf.p + o_rv;
+    dr = *rg;
+    const double** dcols[10] = {&dr.m_g, &dr.m_new, &dr.m_old, &dr.m_co_hi, &dr.h_old, &dr.h_g_i, &dr.tau_i, &dr.l_bol,
+                                &dr.sigma_g, &dr.r_end};
+    for (int k = 0; k < 10; ++k) *dcols[k] = up.buf.p + o_col[k];
+    return hipSuccess;
+}
+
+}  // namespace
+
+int rt_shell_rhs(rt_ctx* ctx, const rt_shell_model* model, const rt_shell_regions* regions, int32_t n,
+                 const int32_t* region, const double* r, const double* v, const double* t, double* dvdr,
+                 double* dtdr) {
+    if (!ctx) return fail(RT_ERR_INVALID, "ctx is NULL");
+    int rc = check_shell_model(model);
+    if (rc == RT_OK) rc = check_shell_regions(regions);
+    if (rc != RT_OK) return rc;
+    if (n < 0 || (n > 0 && (!region || !r || !v || !t || !dvdr || !dtdr))) return fail(RT_ERR_INVALID, "bad argument");
+    if (n == 0) return RT_OK;
+    for (int i = 0; i < n; ++i)
+        if (region[i] < 0 || region[i] >= regions->n) return fail(RT_ERR_INVALID, "point %d names region %d of %d", i, region[i], regions->n);
+    RT_HIP(hipSetDevice(ctx->device));
+    ShellUpload up;
+    rt::ShellModel dm;
+    rt::ShellRegions dr;
+    DevBuf<double> pts;
+    DevBuf<int32_t> idx;
+    hipError_t e = upload_shell(ctx, model, regions, up, dm, dr);
+    if (e == hipSuccess) e = pts.reserve(5 * (size_t)n);
+    if (e == hipSuccess) e = idx.reserve((size_t)n);
+    const double* in[3] = {r, v, t};
+    for (int k = 0; k < 3 && e == hipSuccess; ++k)
+        e = hipMemcpyAsync(pts.p + (size_t)k * n, in[k], sizeof(double) * (size_t)n, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(idx.p, region, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess)
+        e = rt::launch_shell_rhs(dm, dr, n, idx.p, pts.p, pts.p + n, pts.p + 2 * (size_t)n, pts.p + 3 * (size_t)n,
+                                 pts.p + 4 * (size_t)n, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(dvdr, pts.p + 3 * (size_t)n, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(dtdr, pts.p + 4 * (size_t)n, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    up.buf.release();
+    pts.release();
+    idx.release();
+    if (e != hipSuccess) return fail(RT_ERR_DEVICE, "shell right-hand side failed: %s", hipGetErrorString(e));
+    return RT_OK;
+}
+
+int rt_shell_velocity(rt_ctx* ctx, const rt_shell_model* model, const rt_shell_regions* regions,
+                      const rt_shell_control* control, rt_shell_result* out) {
+    if (!ctx || !control || !out) return fail(RT_ERR_INVALID, "NULL argument");
+    int rc = check_shell_model(model);
+    if (rc == RT_OK) rc = check_shell_regions(regions);
+    if (rc != RT_OK) return rc;
+    if (!(control->v0 > 0.0) || !(control->t0 > 0.0) || !(control->rtol > 0.0) || !(control->max_step > 0.0) ||
+        control->atol_v < 0.0 || control->atol_t < 0.0 || control->n_out < 0 || control->max_steps < 1)
+        return fail(RT_ERR_INVALID, "bad integration control");
+    const size_t n = (size_t)regions->n, no = (size_t)control->n_out;
+    if (n == 0) return RT_OK;
+    if (!out->v_max || !out->r_vmax || !out->t_vmax || !out->r_last || !out->v_last || !out->t_last || !out->status ||
+        !out->n_steps || (no > 0 && (!out->v_out || !out->t_out)))
+        return fail(RT_ERR_INVALID, "a result array is NULL");
+    RT_HIP(hipSetDevice(ctx->device));
+    ShellUpload up;
+    rt::ShellModel dm;
+    rt::ShellRegions dr;
+    DevBuf<double> res;
+    DevBuf<int32_t> ires;
+    hipError_t e = upload_shell(ctx, model, regions, up, dm, dr);
+    if (e == hipSuccess) e = res.reserve(6 * n + 2 * n * no + 1);
+    if (e == hipSuccess) e = ires.reserve(2 * n);
+    rt::ShellResult dout;
+    dout.v_max = res.p;
+    dout.r_vmax = res.p + n;
+    dout.t_vmax = res.p + 2 * n;
+    dout.r_last = res.p + 3 * n;
+    dout.v_last = res.p + 4 * n;
+    dout.t_last = res.p + 5 * n;
+    dout.v_out = res.p + 6 * n;
+    dout.t_out = res.p + 6 * n + n * no;
+    dout.status = ires.p;
+    dout.n_steps = ires.p + n;
+    if (e == hipSuccess) e = rt::launch_shell_ode(dm, dr, *control, dout, ctx->stream);
+    double* hd[6] = {out->v_max, out->r_vmax, out->t_vmax, out->r_last, out->v_last, out->t_last};
+    for (int k = 0; k < 6 && e == hipSuccess; ++k)
+        e = hipMemcpyAsync(hd[k], res.p + (size_t)k * n, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && no) e = hipMemcpyAsync(out->v_out, dout.v_out, sizeof(double) * n * no, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && no) e = hipMemcpyAsync(out->t_out, dout.t_out, sizeof(double) * n * no, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out->status, ires.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out->n_steps, ires.p + n, sizeof(int32_t) * n, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    up.buf.release();
+    res.release();
+    ires.release();
+    if (e != hipSuccess) return fail(RT_ERR_DEVICE, "shell integration failed: %s", hipGetErrorString(e));
     return RT_OK;
 }
 

@@ -74,3 +74,19 @@ hipError_t launch_grain_integrals(const GrainSetDev& gs, int n_wl, const double*
                                   int hi_a, double* d_out, hipStream_t stream);
 
 }  // namespace rt
+
+// ---- shell velocity ODE (rt_shell.hip); the structs are the C ABI's with device pointers ----
+namespace rt {
+
+typedef rt_shell_model ShellModel;
+typedef rt_shell_regions ShellRegions;
+typedef rt_shell_control ShellControl;
+typedef rt_shell_result ShellResult;
+
+hipError_t launch_shell_rhs(const ShellModel& m, const ShellRegions& rg, int n, const int32_t* d_region,
+                            const double* d_r, const double* d_v, const double* d_t, double* d_dvdr, double* d_dtdr,
+                            hipStream_t stream);
+hipError_t launch_shell_ode(const ShellModel& m, const ShellRegions& rg, const ShellControl& ct, const ShellResult& out,
+                            hipStream_t stream);
+
+}  // namespace rt
