@@ -207,6 +207,7 @@ def main():
     events_last = int(last[:, A.CNT_SCATTER].sum())
     events_rank_last = events_last / world if world > 1 else events_last  # equal shares by construction
 
+    fast = (cfg["boundary"], cfg["scatter"], cfg["order"]) == ("reflect", "hg", "mc")  # the kernel rt_run picks
     if rank == 0:
         value = events / dt
         achieved = events_rank_last * FP64_OPS_PER_EVENT / (kernel_ms * 1e-3) / 1e12
@@ -224,7 +225,7 @@ def main():
             "roofline": {"bound": "valu_fp64", "achieved": achieved, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_VECTOR_PEAK_TFLOPS,
                          "traffic": measured_traffic(cfg["name"], per_gpu),
-                         "kernel": "walk_kernel", "kernel_avg_ms": kernel_ms, "kernel_launches": launches,
+                         "kernel": "walk_kernel<true>" if fast else "walk_kernel<false>", "kernel_avg_ms": kernel_ms, "kernel_launches": launches,
                          "flop_per_event": FP64_OPS_PER_EVENT},
         }
         out.update(cpu)

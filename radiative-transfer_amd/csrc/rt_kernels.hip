@@ -1,7 +1,7 @@
 // rt_kernels.hip -- gfx950 kernels of the photon random walk and their launchers.
 //
-//   walk_kernel /       persistent scatter kernels (generic / production configuration).
-//   walk_fast_kernel    Every wave pulls work items
+//   walk_kernel<FAST>   persistent scatter kernel (FAST: the production configuration fixed at compile
+//                       time; otherwise every flag read at run time).  Every wave pulls work items
 //                       (atmosphere, chunk of photon ids) from a global queue; inside a
 //                       chunk each lane carries one photon in registers and dead lanes are
 //                       refilled from the chunk with a ballot / prefix count.  A chunk is
@@ -13,6 +13,8 @@
 //
 // Replaces RunPhotons (MC code.py:620-779, Numpy_random_walk.py:280-408) and the
 // atmosphere loop of runMC (MC code.py:1056-1062).
+#include <type_traits>
+
 #include "rt_kernels.hpp"
 
 namespace rt {
@@ -80,6 +82,13 @@ __device__ __forceinline__ void flush_hist(const Hist& h, int lane, int nmu, int
     __builtin_amdgcn_wave_barrier();
 }
 
+// A wave-uniform value moved to scalar registers, so that what is computed from it runs on the scalar unit.
+__device__ __forceinline__ unsigned long long uniform64(unsigned long long v) {
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+
 // One unit of work for a wave: a chunk of consecutive photon ids of one atmosphere.
 struct WorkItem {
     unsigned long long cursor, end;  // photon ids [cursor, end) before id_base is added
@@ -110,12 +119,13 @@ __device__ __forceinline__ bool pop_item(const Sweep& sw, unsigned int* d_next, 
     const unsigned long long slab_lo = slab * plan.slab_len;
     unsigned long long slab_hi = slab_lo + plan.slab_len;
     slab_hi = slab_hi < plan.n_photons ? slab_hi : plan.n_photons;
-    it.cursor = slab_lo + (unsigned long long)c * plan.chunk;
-    const unsigned long long e = it.cursor + plan.chunk;
-    it.end = e < slab_hi ? e : slab_hi;
-    it.tau = plan.tau;
-    it.atm = plan.atm;
-    it.slot = (size_t)plan.slot_base + (size_t)j * plan.chunks_per_slab + c;
+    const unsigned long long first = slab_lo + (unsigned long long)c * plan.chunk;
+    const unsigned long long e = first + plan.chunk;
+    it.cursor = uniform64(first);
+    it.end = uniform64(e < slab_hi ? e : slab_hi);
+    it.tau = __longlong_as_double((long long)uniform64((unsigned long long)__double_as_longlong(plan.tau)));
+    it.atm = __builtin_amdgcn_readfirstlane(plan.atm);
+    it.slot = (size_t)uniform64((unsigned long long)plan.slot_base + (unsigned long long)j * plan.chunks_per_slab + c);
     return true;
 }
 
@@ -157,8 +167,17 @@ __device__ __forceinline__ void store_chunk_wave(const AccWave& acc, const unsig
     flush_hist(hist, lane, nmu, 0, it.atm, n_atm, d_mu_hist, d_depth);
 }
 
-// Generic persistent kernel: every boundary / scattering law / loop order, depth bins, re-emission.
-// Per iteration: refill dead lanes, then one full flight (fly + scatter) per live lane.
+// The persistent walk kernel.  The loop is rotated so that the two lane populations that exist after a
+// flight -- lanes whose photon ended (they need a new photon) and lanes whose photon goes on to
+// scatter -- share ONE Philox call: each lane feeds its own counter (emission block of the new
+// photon id, or the scattering block of the current one) and the 128 output bits are then read
+// as the emission draws or as (azimuth, cosine).  The alias-table entry of the new photons is
+// requested before the scattering arithmetic runs, so the first gather's latency hides under it.
+//   FAST = true   the reference's production configuration fixed at compile time: RT_ORDER_MC, reflecting
+//                 boundary, Henyey-Greenstein, no depth bins, abs_only off; integer tallies per wave.
+//   FAST = false  every boundary / scattering law / loop order, depth bins, re-emission, read from cfg.
+// Both give the same photon histories as one fly() + scatter() per photon per iteration (flight()).
+template <bool FAST>
 __global__ __launch_bounds__(kWalkBlock) void walk_kernel(const Cfg cfg, const Sweep sw,
                                                            unsigned int* __restrict__ d_next,
                                                            double* __restrict__ d_chunk_sums,
@@ -169,7 +188,7 @@ __global__ __launch_bounds__(kWalkBlock) void walk_kernel(const Cfg cfg, const S
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int nmu = cfg.n_mu_bins + 1;
-    const int nd = cfg.n_depth_bins;
+    const int nd = FAST ? 0 : cfg.n_depth_bins;
     const Hist hist = wave_hist(lds_raw, wave, nmu, nd);
     stage_log_table(cfg, lds_raw);
     clear_hist(hist, lane, nmu, nd);
@@ -177,89 +196,9 @@ __global__ __launch_bounds__(kWalkBlock) void walk_kernel(const Cfg cfg, const S
     WorkItem it;
     while (pop_item(sw, d_next, lane, it)) {
         const double tau = it.tau;
-        Acc acc;
+        typename std::conditional<FAST, AccWave, Acc>::type acc;
         acc.clear();
-        Photon ph = {};
-        PhiloxSrc src = {};
-        src.atm = it.atm;
-        src.k0 = cfg.k0;
-        src.k1 = cfg.k1;
-        bool alive = false;
-
-        auto reemit = [&](Photon& p) {
-            const double p0 = p.p0, e1 = p.e1, b = p.b;
-            const uint32_t n_it = p.iter;
-            const int ns = p.n_scatter;
-            emit_from_table(cfg, tau, src, p);
-            p.p0 = p0;
-            p.e1 = e1;
-            p.b = b;
-            p.iter = n_it;
-            p.n_scatter = ns;
-        };
-
-        for (;;) {
-            // ---- refill dead lanes from the chunk (ballot + prefix count) ----
-            const unsigned long long dead = __ballot(!alive);
-            if (dead != 0ull && it.cursor < it.end) {
-                const unsigned int my_off =
-                    __builtin_amdgcn_mbcnt_hi((uint32_t)(dead >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dead, 0u));
-                const unsigned long long my_id = it.cursor + my_off;
-                if (!alive && my_id < it.end) {
-                    const unsigned long long gid = my_id + cfg.id_base;
-                    src.id_lo = (uint32_t)gid;
-                    src.id_hi = (uint32_t)(gid >> 32);
-                    src.blk = 0u;
-                    src.n_emit = 0u;
-                    emit_from_table(cfg, tau, src, ph);
-                    start_photon(ph, acc);
-                    alive = true;
-                }
-                it.cursor += (unsigned long long)__popcll(dead);
-            }
-            if (__ballot(alive) == 0ull) break;
-            // ---- one flight for every live lane ----
-            if (alive) {
-                const int fate = flight<false>(cfg, ph, src, acc, hist, reemit);
-                if (fate != 0) {
-                    retire(cfg, ph, fate, acc, hist);
-                    alive = false;
-                }
-            }
-        }
-        store_chunk(acc, it, hist, lane, nmu, nd, sw.n_atm, d_chunk_sums, d_counts, d_mu_hist, d_depth);
-    }
-}
-
-// Fast persistent kernel for the reference's production configuration: RT_ORDER_MC, reflecting
-// boundary, Henyey-Greenstein, no depth bins, abs_only off.  Same photon histories and tallies as
-// walk_kernel, but the loop is rotated so that the two lane populations that exist after a
-// flight -- lanes whose photon ended (they need a new photon) and lanes whose photon goes on to
-// scatter -- share ONE Philox call: each lane feeds its own counter (emission block of the new
-// photon id, or the scattering block of the current one) and the 128 output bits are then read
-// as the emission draws or as (azimuth, cosine).  The alias-table entry of the new photons is
-// requested before the scattering arithmetic runs, so the first gather's latency hides under it.
-__global__ __launch_bounds__(kWalkBlock) void walk_fast_kernel(const Cfg cfg, const Sweep sw,
-                                                                unsigned int* __restrict__ d_next,
-                                                                double* __restrict__ d_chunk_sums,
-                                                                unsigned long long* __restrict__ d_counts,
-                                                                unsigned long long* __restrict__ d_mu_hist,
-                                                                double* __restrict__ d_depth) {
-    extern __shared__ __align__(16) unsigned char lds_raw[];
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int nmu = cfg.n_mu_bins + 1;
-    const Hist hist = wave_hist(lds_raw, wave, nmu, 0);
-    stage_log_table(cfg, lds_raw);
-    clear_hist(hist, lane, nmu, 0);
-    auto no_reemit = [](Photon&) {};
-
-    WorkItem it;
-    while (pop_item(sw, d_next, lane, it)) {
-        const double tau = it.tau;
-        AccWave acc;
-        acc.clear();
-        unsigned long long wc[RT_NCNT] = {};  // wave totals, the same value in every lane
+        unsigned long long wc[RT_NCNT] = {};  // FAST: wave totals, the same value in every lane
         Photon ph = {};
         PhiloxSrc src = {};
         src.atm = it.atm;
@@ -267,10 +206,25 @@ __global__ __launch_bounds__(kWalkBlock) void walk_fast_kernel(const Cfg cfg, co
         src.k1 = cfg.k1;
         bool alive = false;  // at the top of the loop a live lane is one that must scatter
 
+        // CheckBoundary 'reemit' (MC code.py:539-547): fresh table values and direction, same history
+        auto reemit = [&](Photon& p) {
+            if (!FAST) {
+                const double p0 = p.p0, e1 = p.e1, b = p.b;
+                const uint32_t n_it = p.iter;
+                const int ns = p.n_scatter;
+                emit_from_table(cfg, tau, src, p);
+                p.p0 = p0;
+                p.e1 = e1;
+                p.b = b;
+                p.iter = n_it;
+                p.n_scatter = ns;
+            }
+        };
+
         for (;;) {
             // ---- hand new photon ids to dead lanes (ballot + prefix count) ----
             bool fresh = false;
-            const unsigned long long dead = __ballot(!alive);
+            const unsigned long long dead = __builtin_amdgcn_ballot_w64(!alive);
             if (dead != 0ull && it.cursor < it.end) {
                 const unsigned int my_off =
                     __builtin_amdgcn_mbcnt_hi((uint32_t)(dead >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dead, 0u));
@@ -280,15 +234,18 @@ __global__ __launch_bounds__(kWalkBlock) void walk_fast_kernel(const Cfg cfg, co
                     src.id_lo = (uint32_t)gid;
                     src.id_hi = (uint32_t)(gid >> 32);
                     src.blk = 0u;
+                    src.n_emit = 1u;  // the emission block of this iteration is number 0
                     fresh = true;
                 }
                 it.cursor += (unsigned long long)__popcll(dead);
             }
             const bool active = alive || fresh;
-            if (__ballot(active) == 0ull) break;
-            // integer tallies as population counts of lane masks, taken here where every lane of the wave arrives
-            wc[RT_CNT_PHOTONS] += (unsigned long long)__popcll(__builtin_amdgcn_ballot_w64(fresh));
-            wc[RT_CNT_SCATTER] += (unsigned long long)__popcll(__builtin_amdgcn_ballot_w64(alive));
+            if (__builtin_amdgcn_ballot_w64(active) == 0ull) break;
+            if (FAST) {
+                // integer tallies as population counts of lane masks, taken where every lane of the wave arrives
+                wc[RT_CNT_PHOTONS] += (unsigned long long)__popcll(__builtin_amdgcn_ballot_w64(fresh));
+                wc[RT_CNT_SCATTER] += (unsigned long long)__popcll(__builtin_amdgcn_ballot_w64(alive));
+            }
             int fate = 0;
             bool flew = false;
             if (active) {
@@ -303,16 +260,17 @@ __global__ __launch_bounds__(kWalkBlock) void walk_fast_kernel(const Cfg cfg, co
                 bucket = bucket < cfg.n_wl ? bucket : cfg.n_wl - 1;
                 bucket = fresh ? bucket : 0;
                 const uint4 raw = *reinterpret_cast<const uint4*>(&cfg.alias[bucket]);
+                int scatter_fate = 0;
                 if (!fresh) {
                     ++src.blk;
-                    scatter<true>(cfg, ph, src, ua, ub, 2, acc, hist);
+                    scatter_fate = scatter<FAST>(cfg, ph, src, ua, ub, 2, acc, hist);
                 }
                 const double prob = __hiloint2double((int)raw.y, (int)raw.x);
                 int idx = (xb - (double)bucket) < prob ? bucket : (int)raw.z;
                 idx = cfg.mono_index >= 0 ? cfg.mono_index : idx;
                 idx = fresh ? idx : 0;
                 const TableRec rec = load_record(cfg, idx);
-                const bool guard = !fresh && ph.iter >= (uint32_t)cfg.max_events;
+                const bool guard = scatter_fate != 0 || (!fresh && ph.iter >= (uint32_t)cfg.max_events);
                 double u_step, u_abs;
                 src.pair(u_step, u_abs);
                 if (fresh) {
@@ -324,22 +282,28 @@ __global__ __launch_bounds__(kWalkBlock) void walk_fast_kernel(const Cfg cfg, co
                 if (!guard) {
                     flew = true;
                     int n_used = 0;
-                    fate = fly<true>(cfg, ph, u_step, u_abs, 2, false, acc, hist, no_reemit, n_used);
+                    fate = fly<FAST>(cfg, ph, u_step, u_abs, 2, false, acc, hist, reemit, n_used);
                 }
                 if (fate != 0) {
                     retire(cfg, ph, fate, acc, hist);
                     alive = false;
                 }
             }
-            wc[RT_CNT_FLIGHTS] += (unsigned long long)__popcll(__builtin_amdgcn_ballot_w64(flew));
-            wc[RT_CNT_ESCAPED] += (unsigned long long)__popcll(__builtin_amdgcn_ballot_w64(fate == RT_FATE_ESCAPED));
-            wc[RT_CNT_ESCAPED_UNCOUNTED] +=
-                (unsigned long long)__popcll(__builtin_amdgcn_ballot_w64(fate == RT_FATE_ESCAPED_UNCOUNTED));
-            wc[RT_CNT_GUARD] += (unsigned long long)__popcll(__builtin_amdgcn_ballot_w64(fate == RT_FATE_GUARD));
+            if (FAST) {
+                wc[RT_CNT_FLIGHTS] += (unsigned long long)__popcll(__builtin_amdgcn_ballot_w64(flew));
+                wc[RT_CNT_ESCAPED] += (unsigned long long)__popcll(__builtin_amdgcn_ballot_w64(fate == RT_FATE_ESCAPED));
+                wc[RT_CNT_ESCAPED_UNCOUNTED] +=
+                    (unsigned long long)__popcll(__builtin_amdgcn_ballot_w64(fate == RT_FATE_ESCAPED_UNCOUNTED));
+                wc[RT_CNT_GUARD] += (unsigned long long)__popcll(__builtin_amdgcn_ballot_w64(fate == RT_FATE_GUARD));
+            }
         }
-        // every photon started in this chunk also ended in it
-        wc[RT_CNT_ABSORBED] = wc[RT_CNT_PHOTONS] - wc[RT_CNT_ESCAPED] - wc[RT_CNT_ESCAPED_UNCOUNTED] - wc[RT_CNT_GUARD];
-        store_chunk_wave(acc, wc, it, hist, lane, nmu, sw.n_atm, d_chunk_sums, d_counts, d_mu_hist, d_depth);
+        if constexpr (FAST) {
+            // every photon started in this chunk also ended in it
+            wc[RT_CNT_ABSORBED] = wc[RT_CNT_PHOTONS] - wc[RT_CNT_ESCAPED] - wc[RT_CNT_ESCAPED_UNCOUNTED] - wc[RT_CNT_GUARD];
+            store_chunk_wave(acc, wc, it, hist, lane, nmu, sw.n_atm, d_chunk_sums, d_counts, d_mu_hist, d_depth);
+        } else {
+            store_chunk(acc, it, hist, lane, nmu, nd, sw.n_atm, d_chunk_sums, d_counts, d_mu_hist, d_depth);
+        }
     }
 }
 
@@ -547,8 +511,8 @@ size_t walk_lds_bytes(const Cfg& cfg, bool fast) {
 
 int walk_max_blocks_per_cu(bool fast, size_t lds_bytes) {
     int nb = 0;
-    hipError_t e = fast ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, walk_fast_kernel, kWalkBlock, lds_bytes)
-                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, walk_kernel, kWalkBlock, lds_bytes);
+    hipError_t e = fast ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, walk_kernel<true>, kWalkBlock, lds_bytes)
+                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, walk_kernel<false>, kWalkBlock, lds_bytes);
     if (e != hipSuccess || nb < 1) nb = 1;
     return nb;
 }
@@ -558,9 +522,9 @@ hipError_t launch_walk(const Cfg& cfg, const Sweep& sw, bool fast, int grid, hip
                        unsigned long long* d_mu_hist, double* d_depth) {
     const size_t lds = walk_lds_bytes(cfg, fast);
     if (fast)
-        walk_fast_kernel<<<grid, kWalkBlock, lds, stream>>>(cfg, sw, d_next, d_chunk_sums, d_counts, d_mu_hist, d_depth);
+        walk_kernel<true><<<grid, kWalkBlock, lds, stream>>>(cfg, sw, d_next, d_chunk_sums, d_counts, d_mu_hist, d_depth);
     else
-        walk_kernel<<<grid, kWalkBlock, lds, stream>>>(cfg, sw, d_next, d_chunk_sums, d_counts, d_mu_hist, d_depth);
+        walk_kernel<false><<<grid, kWalkBlock, lds, stream>>>(cfg, sw, d_next, d_chunk_sums, d_counts, d_mu_hist, d_depth);
     return hipGetLastError();
 }
 
