@@ -32,6 +32,36 @@ def test_struct_layout_matches_header(rt):
     assert A.RtParams.seed.offset == 48 and A.RtParams.tau_atm.offset == 88
 
 
+def test_header_is_plain_c_and_layouts_match_ctypes(rt, tmp_path):
+    """include/rt_amd.h compiles as C11 with gcc, and every struct has the size and field offsets of its
+    ctypes mirror."""
+    import subprocess
+    A = rt._abi
+    pairs = {"rt_params": A.RtParams, "rt_tallies": A.RtTallies, "rt_photon_trace": A.RtPhotonTrace,
+             "rt_grain_set": A.RtGrainSet, "rt_grain_tables": A.RtGrainTables, "rt_shell_model": A.RtShellModel,
+             "rt_shell_regions": A.RtShellRegions, "rt_shell_control": A.RtShellControl, "rt_shell_result": A.RtShellResult}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "rt_amd.h"', 'int main(void) {']
+    for cname, ct in pairs.items():
+        lines.append(f'printf("{cname} size %zu\\n", sizeof({cname}));')
+        for fname, _ in ct._fields_:
+            lines.append(f'printf("{cname} {fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ['return 0;', '}']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c11", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)],
+                   check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split("\n")
+    seen = 0
+    for line in filter(None, out):
+        cname, field, value = line.split()
+        ct = pairs[cname]
+        want = ctypes.sizeof(ct) if field == "size" else getattr(ct, field).offset
+        assert int(value) == want, line
+        seen += 1
+    assert seen == sum(len(ct._fields_) + 1 for ct in pairs.values())
+
+
 def test_no_cpu_fallback(rt):
     """Without a GPU the engine must refuse to start rather than compute on the host."""
     import torch
