@@ -108,16 +108,6 @@ def test_known_answers_of_the_reference_run(engine):
     assert np.all(sol.v_max[still] <= float(Z["v_0"]) * (1 + 1e-12)) and np.all(sol.r_last[still] < 5.01 * CM_PC)
 
 
-def test_host_get_mc_and_tau_ir(engine):
-    m = make_model(False)
-    tau = np.array([1e-8, 3.3e-4, 0.07, 2.0, 55.0, 1e11])
-    for age in (6.0, 6.37, 9.9):
-        want = [shell_ode.get_mc(shell_ode.Model(Z), float(x), age) for x in tau]
-        np.testing.assert_allclose(shell.get_mc(m, tau, age), want, rtol=1e-13)
-    r, lb, sg = 7 * CM_PC, 3e41, 0.2
-    assert shell.get_tau_ir(r, lb, sg) == pytest.approx(shell_ode.get_tau_ir(r, lb, sg), rel=1e-14)
-
-
 def test_errors(rt, engine):
     with pytest.raises(ValueError):
         shell.ShellModel(Z["mc_tau"], Z["mc_ages"], Z["mc_values"], stellar_aging=True)

@@ -5,7 +5,11 @@ import os
 import numpy as np
 import pytest
 
+import importlib
+
 from oracle import shell_ode
+
+shell = importlib.import_module("radiative-transfer_amd.shell")
 
 Z = np.load(os.path.join(os.path.dirname(__file__), "golden", "shell.npz"))
 CASES = [str(c) for c in Z["rhs_case_names"]]
@@ -51,3 +55,24 @@ def test_trajectories_match_reference():
         np.testing.assert_allclose(v[ok], want_v[ok], rtol=1e-6, atol=5e-6 * np.nanmax(want_v))  # a stalling shell: v -> 0
         np.testing.assert_allclose(t[ok], want_t[ok], rtol=5e-6)
         assert abs(r_stop - Z["traj_rstop"][k]) <= 1e-3 * Z["traj_rstop"][k]
+
+
+def test_host_get_mc_and_tau_ir():
+    m = shell.ShellModel(Z["mc_tau"], Z["mc_ages"], Z["mc_values"], time_slice=float(Z["time_slice"]))
+    tau = np.array([1e-8, 3.3e-4, 0.07, 2.0, 55.0, 1e11])
+    for age in (6.0, 6.37, 9.9):
+        want = [shell_ode.get_mc(shell_ode.Model(Z), float(x), age) for x in tau]
+        np.testing.assert_allclose(shell.get_mc(m, tau, age), want, rtol=1e-13)
+    r, lb, sg = 7 * shell.CM_PC, 3e41, 0.2
+    assert shell.get_tau_ir(r, lb, sg) == pytest.approx(shell_ode.get_tau_ir(r, lb, sg), rel=1e-14)
+
+
+def test_host_ratio_and_cutoff():
+    ratio = shell.ratio_rp_lambda_rp({k: Z[k] for k in ("kappa_av_RP_Sil", "kappa_av_RP_Gra", "kappa_av_RP_SiC")},
+                                     float(Z["kappa_rp_ref"]))
+    m = shell.ShellModel(Z["mc_tau"], Z["mc_ages"], Z["mc_values"], time_slice=6.0, tau_cutoff=0.5, l_ages=Z["l_ages"],
+                         ratio_values=ratio)
+    ref = shell_ode.Model(Z, tau_cutoff=0.5)
+    tau = np.array([1e-5, 0.01, 0.3, 4.0])
+    for age in (6.0, 7.25):
+        np.testing.assert_allclose(shell.get_mc(m, tau, age), [shell_ode.get_mc(ref, float(x), age) for x in tau], rtol=1e-13)
