@@ -19,6 +19,19 @@ namespace rt {
 //   ln x = e ln2 + L[j] + log1p(r),   L[j] = -ln(inv_c[j]) for the ROUNDED inv_c[j]
 // The 128-entry table {inv_c, L} (2 KiB) is staged in LDS once per workgroup.
 // ---------------------------------------------------------------------------
+// a*b + c with the constant addend read in place (VOP3 v_fma_f64).  The compiler's choice for a Horner
+// step is the two-address v_fmac_f64, which first copies the coefficient into the destination: one extra
+// 4-cycle v_mov_b64 per step.
+__device__ __forceinline__ double fma_step(double a, double b, double c) {
+#ifdef RT_PLAIN_FMA
+    return fma(a, b, c);
+#else
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+#endif
+}
+
 constexpr int kLogTableEntries = 128;
 
 struct LogTableEntry {
@@ -34,11 +47,11 @@ __device__ __forceinline__ double log_unit(double x, const LogTableEntry* __rest
     const double m = __hiloint2double((int)((hi & 0x000FFFFFu) | 0x3FF00000u), (int)lo);
     const LogTableEntry t = lds_table[j];
     const double r = fma(m, t.inv_c, -1.0);
-    double p = fma(r, 1.0 / 7.0, -1.0 / 6.0);
-    p = fma(r, p, 1.0 / 5.0);
-    p = fma(r, p, -1.0 / 4.0);
-    p = fma(r, p, 1.0 / 3.0);
-    p = fma(r, p, -0.5);
+    double p = fma_step(r, 1.0 / 7.0, -1.0 / 6.0);
+    p = fma_step(r, p, 1.0 / 5.0);
+    p = fma_step(r, p, -1.0 / 4.0);
+    p = fma_step(r, p, 1.0 / 3.0);
+    p = fma_step(r, p, -0.5);
     const double r2 = r * r;
     p = fma(r2, p, r);  // log1p(r)
     const double ed = (double)e;
@@ -60,13 +73,13 @@ __device__ __forceinline__ double cos_2pi(double u) {
     const double k = rint(t);
     const double w = t - k;
     const double z = w * w;
-    double r = fma(z, 4.16639726608991643254e-06, -1.04582860367372637990e-04);
-    r = fma(z, r, 1.92956265087559594197e-03);
-    r = fma(z, r, -2.58068900255420882739e-02);
-    r = fma(z, r, 2.35330630272128971114e-01);
-    r = fma(z, r, -1.33526276885187988874e+00);
-    r = fma(z, r, 4.05871212641673650978e+00);
-    r = fma(z, r, -4.93480220054467899615e+00);
+    double r = fma_step(z, 4.16639726608991643254e-06, -1.04582860367372637990e-04);
+    r = fma_step(z, r, 1.92956265087559594197e-03);
+    r = fma_step(z, r, -2.58068900255420882739e-02);
+    r = fma_step(z, r, 2.35330630272128971114e-01);
+    r = fma_step(z, r, -1.33526276885187988874e+00);
+    r = fma_step(z, r, 4.05871212641673650978e+00);
+    r = fma_step(z, r, -4.93480220054467899615e+00);
     const double c = fma(z, r, 1.0);
     const uint32_t sign = (uint32_t)(int)k << 31;  // k odd: negate
     return __hiloint2double((int)((uint32_t)__double2hiint(c) ^ sign), __double2loint(c));
