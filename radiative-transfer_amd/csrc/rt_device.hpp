@@ -118,12 +118,15 @@ struct Acc {
 #pragma unroll
         for (int k = 0; k < RT_NCNT; ++k) c[k] = 0u;
     }
+    __device__ __forceinline__ void add(int k, double v) { s[k] += v; }
     __device__ __forceinline__ void count(int k) { c[k]++; }
     __device__ __forceinline__ void count_if(int k, bool p) { c[k] += p; }
 };
 
 // Tallies of the fast kernel: the integer tallies other than the boundary hits are counted per WAVE by the
 // kernel itself (population counts of lane masks, scalar registers), so the per-lane hooks do nothing.
+// (Keeping the floating-point sums in LDS slots updated with ds_add_f64 instead of registers was measured:
+// 16 fewer vector registers and 10 fewer vector instructions per iteration, no change in run time.)
 struct AccWave {
     double s[RT_NSUM];
     uint32_t hits;
@@ -132,6 +135,7 @@ struct AccWave {
         for (int k = 0; k < RT_NSUM; ++k) s[k] = 0.0;
         hits = 0u;
     }
+    __device__ __forceinline__ void add(int k, double v) { s[k] += v; }
     __device__ __forceinline__ void count(int k) {
         if (k == RT_CNT_BOUNDARY_HITS) hits++;
     }
@@ -313,7 +317,7 @@ __device__ __forceinline__ int fly(const Cfg& cfg, Photon& ph, double u_step, do
             ph.b += pb;
             acc.count(RT_CNT_REEMITTED);
             reemit(ph);
-            acc.s[RT_SUM_REEMITTED] += ph.mu * ph.wh;
+            acc.add(RT_SUM_REEMITTED, ph.mu * ph.wh);
         }
     }
     if (ph.z > ph.zmax) {  // second escape test (the only one in gray order)
@@ -321,7 +325,7 @@ __device__ __forceinline__ int fly(const Cfg& cfg, Photon& ph, double u_step, do
             ph.e1 = ph.mu * ph.wh;
             return RT_FATE_ESCAPED;
         }
-        acc.s[RT_SUM_ESCAPED_UNCOUNTED] += ph.mu * ph.wh;
+        acc.add(RT_SUM_ESCAPED_UNCOUNTED, ph.mu * ph.wh);
         return RT_FATE_ESCAPED_UNCOUNTED;
     }
 
@@ -331,8 +335,8 @@ __device__ __forceinline__ int fly(const Cfg& cfg, Photon& ph, double u_step, do
     const bool absorbed = (!FAST && cfg.abs_only) ? (u_abs > 0.0) : (u_abs > ph.albedo);
     if (absorbed) {
         const double pa = ph.mu * ph.wh;
-        acc.s[RT_SUM_DUST_MOMENTUM] += pa;
-        acc.s[RT_SUM_ABSORBED_ENERGY] += ph.wh;
+        acc.add(RT_SUM_DUST_MOMENTUM, pa);
+        acc.add(RT_SUM_ABSORBED_ENERGY, ph.wh);
         if (depth) {
             const int k = depth_bin(cfg, ph);
             atomicAdd(&hist.depth_mom[k], pa);
@@ -402,7 +406,7 @@ __device__ __forceinline__ int scatter(const Cfg& cfg, Photon& ph, Src& src, dou
     ph.n_scatter++;
     acc.count(RT_CNT_SCATTER);
     const double dp = (mu_old - mu_new) * ph.wh;
-    acc.s[RT_SUM_DUST_MOMENTUM] += dp;
+    acc.add(RT_SUM_DUST_MOMENTUM, dp);
     if (depth) atomicAdd(&hist.depth_mom[depth_bin(cfg, ph)], dp);
     return 0;
 }
@@ -432,12 +436,12 @@ __device__ __forceinline__ void retire(const Cfg& cfg, const Photon& ph, int fat
     acc.count_if(RT_CNT_ABSORBED, fate == RT_FATE_ABSORBED);
     acc.count_if(RT_CNT_BOUNDARY_ABSORBED, fate == RT_FATE_BOUNDARY);
     acc.count_if(RT_CNT_GUARD, fate == RT_FATE_GUARD);
-    acc.s[RT_SUM_ESCAPED] += ph.e1;
-    acc.s[RT_SUM_BOUNDARY] += ph.b;
+    acc.add(RT_SUM_ESCAPED, ph.e1);
+    acc.add(RT_SUM_BOUNDARY, ph.b);
     const double t = ph.p0 - ph.e1 + ph.b;
-    acc.s[RT_SUM_TRANSFER_SQ] += t * t;
-    acc.s[RT_SUM_TRANSFER_P0] += t * ph.p0;
-    acc.s[RT_SUM_P0_SQ] += ph.p0 * ph.p0;
+    acc.add(RT_SUM_TRANSFER_SQ, t * t);
+    acc.add(RT_SUM_TRANSFER_P0, t * ph.p0);
+    acc.add(RT_SUM_P0_SQ, ph.p0 * ph.p0);
     if (hist.mu && ((fate == RT_FATE_ESCAPED && gray) || fate == RT_FATE_ESCAPED_UNCOUNTED)) {
         int k = (int)floor((double)cfg.n_mu_bins * ph.mu);
         k = k < 0 ? 0 : k;
@@ -453,7 +457,7 @@ __device__ __forceinline__ void start_photon(Photon& ph, AccT& acc) {
     ph.b = 0.0;
     ph.iter = 0u;
     ph.n_scatter = 0;
-    acc.s[RT_SUM_INITIAL] += ph.p0;
+    acc.add(RT_SUM_INITIAL, ph.p0);
     acc.count(RT_CNT_PHOTONS);
 }
 
