@@ -104,6 +104,8 @@ __global__ __launch_bounds__(256) void k_cnd_sgpr(uint32_t* out, unsigned long l
 // 32-bit VOP2 with an SGPR operand and with a literal (the forms Philox key xors take)
 KERNEL32(k_xor_sgpr, "v_xor_b32 %0, s20, %0\n v_xor_b32 %1, s20, %1\n v_xor_b32 %2, s20, %2\n v_xor_b32 %3, s20, %3\n")
 KERNEL32(k_xor_lit, "v_xor_b32 %0, 0x9E3779B9, %0\n v_xor_b32 %1, 0x9E3779B9, %1\n v_xor_b32 %2, 0x9E3779B9, %2\n v_xor_b32 %3, 0x9E3779B9, %3\n")
+KERNEL32(k_bitop3, "v_bitop3_b32 %0, %0, %4, %1 bitop3:0x96\n v_bitop3_b32 %1, %1, %4, %2 bitop3:0x96\n v_bitop3_b32 %2, %2, %4, %3 bitop3:0x96\n v_bitop3_b32 %3, %3, %4, %0 bitop3:0x96\n")
+KERNEL32(k_bitop3_sgpr, "v_bitop3_b32 %0, %0, %4, s20 bitop3:0x96\n v_bitop3_b32 %1, %1, %4, s20 bitop3:0x96\n v_bitop3_b32 %2, %2, %4, s20 bitop3:0x96\n v_bitop3_b32 %3, %3, %4, s20 bitop3:0x96\n")
 KERNEL32(k_lshl_add, "v_lshl_add_u32 %0, %0, 3, %4\n v_lshl_add_u32 %1, %1, 3, %4\n v_lshl_add_u32 %2, %2, 3, %4\n v_lshl_add_u32 %3, %3, 3, %4\n")
 KERNEL32(k_lshr, "v_lshrrev_b32 %0, 5, %0\n v_lshrrev_b32 %1, 5, %1\n v_lshrrev_b32 %2, 5, %2\n v_lshrrev_b32 %3, 5, %3\n")
 KERNEL64(k_fmac64, "v_fmac_f64 %0, %4, %4\n v_fmac_f64 %1, %4, %4\n v_fmac_f64 %2, %4, %4\n v_fmac_f64 %3, %4, %4\n")
@@ -160,7 +162,7 @@ int main() {
 #define RUN(k) run(#k, k, 4, d_out, d_clk)
     RUN(k_xor); RUN(k_add); RUN(k_mov); RUN(k_cnd); RUN(k_alignbit); RUN(k_cmp); RUN(k_mullo); RUN(k_mulhi);
     RUN(k_mad64); RUN(k_fma64); RUN(k_add64); RUN(k_mul64); RUN(k_mov64); RUN(k_rcp64); RUN(k_rndne64); RUN(k_cmp64);
-    RUN(k_cnd_vcc); RUN(k_cnd_sgpr); RUN(k_xor_sgpr); RUN(k_xor_lit); RUN(k_lshl_add); RUN(k_lshr); RUN(k_fmac64); RUN(k_ldexp64); RUN(k_rsq64);
+    RUN(k_bitop3); RUN(k_bitop3_sgpr); RUN(k_cnd_vcc); RUN(k_cnd_sgpr); RUN(k_xor_sgpr); RUN(k_xor_lit); RUN(k_lshl_add); RUN(k_lshr); RUN(k_fmac64); RUN(k_ldexp64); RUN(k_rsq64);
     RUN(k_mad64_sgpr); RUN(k_fma64_sgpr); RUN(k_fma64_inl); RUN(k_cnd_e64vcc); RUN(k_add_lit); RUN(k_add_inl); RUN(k_xor_mix);
     run("k_fma64dep (1 wave)", k_fma64dep, 1, d_out, d_clk);
     run("k_fma64dep", k_fma64dep, 4, d_out, d_clk);
