@@ -164,7 +164,10 @@ int rt_run(rt_ctx* ctx, const rt_params* p, rt_tallies* out);
  * d_slab_sums  [n_atm][n_slabs][RT_NSUM] doubles, d_counts [n_atm][RT_NCNT] u64,
  * d_mu_hist [n_atm][n_mu_bins+1] u64, d_depth [2][n_atm][n_depth_bins] doubles (may be NULL when
  * n_depth_bins == 0).  Buffers are overwritten (zeroed, then filled with this rank's share). The work
- * is enqueued on `stream` (a hipStream_t passed as void*; NULL = default stream) and NOT synchronised. */
+ * is enqueued on `stream` (a hipStream_t passed as void*; NULL = default stream) and NOT synchronised.
+ * A context owns one set of device work buffers (work queue, chunk partial sums): successive calls on one
+ * context must go to the same stream, or the caller orders them itself (event or synchronise) -- two
+ * sweeps of one context in flight on different streams race.  Use one context per concurrent stream. */
 int rt_run_device(rt_ctx* ctx, const rt_params* p, void* d_slab_sums, void* d_counts, void* d_mu_hist,
                   void* d_depth, void* stream);
 

@@ -207,6 +207,7 @@ int rt_create(rt_ctx** out, int device_id) {
     e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->staged, hipEventDisableTiming);
     if (e != hipSuccess) {
+        if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
         delete ctx;
         return fail(RT_ERR_DEVICE, "hipStreamCreate / hipEventCreate: %s", hipGetErrorString(e));
     }
