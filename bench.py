@@ -106,6 +106,8 @@ def main():
     ap.add_argument("--cpu-photons", type=int, default=1000000)
     ap.add_argument("--cpu-procs", type=int, default=0, help="processes of the all-cores CPU baseline (0 = min(16, cores))")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--rng", choices=["philox52", "philox32x4"], default="philox52",
+                    help="philox32x4 = the opt-in one-block-per-iteration stream with 32-bit uniforms (not the headline)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo stages the tallies through host memory; for rehearsing N > 1 on a box with fewer GPUs than ranks")
     args = ap.parse_args()
@@ -165,7 +167,7 @@ def main():
     def step(i):
         prm = rt.make_params(tau, total_photons, boundary=cfg["boundary"], scatter=cfg["scatter"], order=cfg["order"],
                              n_mu_bins=10, n_slabs=n_slabs, rank=rank, world=world, h=cfg["h"],
-                             monochromatic=cfg["monochromatic"], photon_id_base=i * total_photons)
+                             monochromatic=cfg["monochromatic"], photon_id_base=i * total_photons, rng=args.rng)
         eng.run_device(prm, slab.data_ptr(), counts.data_ptr(), hist.data_ptr(), None, stream)
         if world > 1:
             # every slab entry is non-zero on exactly one rank, so the sum is exact and order-free
@@ -220,12 +222,14 @@ def main():
                                    f"{per_gpu:.3g} photons per atmosphere per GPU, {cfg['describe']}",
                        "photons_per_atmosphere_global": total_photons, "photon_histories_per_step": int(last[:, A.CNT_PHOTONS].sum()),
                        "flights_per_step": int(last[:, A.CNT_FLIGHTS].sum()), "events_per_step": events_last,
+                       "rng": "Philox4x32-10, " + ("52-bit uniforms, 2 blocks per loop iteration" if args.rng == "philox52"
+                                                   else "32-bit uniforms, 1 block per loop iteration (opt-in mode)"),
                        "parallelism": f"photon-id slabs over {world} GPU(s), 1 all-reduce of tallies per step"},
             "photon_histories_per_s": float(last[:, A.CNT_PHOTONS].sum()) * args.steps / dt,
             "roofline": {"bound": "valu_fp64", "achieved": achieved, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_VECTOR_PEAK_TFLOPS,
                          "traffic": measured_traffic(cfg["name"], per_gpu),
-                         "kernel": "walk_kernel<true>" if fast else "walk_kernel<false>", "kernel_avg_ms": kernel_ms, "kernel_launches": launches,
+                         "kernel": f"walk_kernel<{'true' if fast else 'false'}, {'true' if args.rng == 'philox32x4' else 'false'}>", "kernel_avg_ms": kernel_ms, "kernel_launches": launches,
                          "flop_per_event": FP64_OPS_PER_EVENT},
         }
         out.update(cpu)

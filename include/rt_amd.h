@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 1
+#define RT_ABI_VERSION 2
 
 typedef enum rt_status {
     RT_OK = 0,
@@ -90,6 +90,16 @@ enum {
 };
 
 /* One sweep over n_atm atmospheres (the loop of runMC, MC code.py:1056-1062). */
+/* How uniforms are cut from the Philox4x32-10 stream of a photon (counter = id, block, atmosphere).
+ * RT_RNG_PHILOX52 (default): every uniform has 52 random bits (two words); loop iteration k uses block 2k
+ *   for (step, absorb) and block 2k+1 for (azimuth, cosine); emission draws come from blocks >= 2^31.
+ * RT_RNG_PHILOX32X4 (opt-in, faster): ONE block per loop iteration, one 32-bit word per uniform,
+ *   u = (w + 1/2) / 2^32: block k gives (azimuth, cosine) of the scattering BEFORE flight k in words 0-1 and
+ *   (step, absorb) of flight k in words 2-3; block 0's words 0-1 (no scattering precedes the first flight)
+ *   are the 52-bit emission draw.  Steps are then quantised to 2^-32 in xi (longest step 22.9), angles to
+ *   2^-32 of a turn.  Not available with RT_SCATTER_DRAINE. */
+enum rt_rng_mode { RT_RNG_PHILOX52 = 0, RT_RNG_PHILOX32X4 = 1 };
+
 typedef struct rt_params {
     int32_t n_atm;
     int32_t boundary;              /* RT_BOUNDARY_* ; reference flag `boundary`, MC code.py:78 */
@@ -110,6 +120,8 @@ typedef struct rt_params {
     double h;                      /* Planck constant used in GetZMomentum (constants.py:10; 1 in the gray script) */
     const double* tau_atm;         /* [n_atm] reference optical depth of each atmosphere (tau_list_calc) */
     const uint64_t* n_photons;     /* [n_atm] photons per atmosphere (photon_reduction already applied) */
+    int32_t rng_mode;              /* RT_RNG_* */
+    int32_t reserved_;             /* 0 */
 } rt_params;
 
 /* Host-side result arrays of one sweep; any pointer may be NULL to skip it. */

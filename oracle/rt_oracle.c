@@ -58,6 +58,15 @@ static double u52(uint32_t a, uint32_t b) {
     return (double)(((uint64_t)a << 20) | (uint64_t)(b >> 12)) / 4503599627370496.0;
 }
 
+/* RT_RNG_PHILOX32X4: one word per uniform, (w + 1/2) / 2^32 */
+static double u32mid(uint32_t w) { return ((double)w + 0.5) / 4294967296.0; }
+
+static void block_words(uint64_t id, uint32_t block, uint32_t atm, uint64_t seed, uint32_t w[4]) {
+    uint32_t ctr[4] = {(uint32_t)id, (uint32_t)(id >> 32), block, atm};
+    uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    ora_philox4x32_10(ctr, key, w);
+}
+
 static void block_uniforms(uint64_t id, uint32_t block, uint32_t atm, uint64_t seed, double* ua, double* ub) {
     uint32_t ctr[4] = {(uint32_t)id, (uint32_t)(id >> 32), block, atm};
     uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
@@ -152,11 +161,23 @@ typedef struct {
     int have_block;
     uint32_t cur_block;
     double ua, ub;
+    /* RT_RNG_PHILOX32X4: walk draw j (0 step, 1 absorb, 2 azimuth, 3 cosine, 4 step, ...) is word (j + 2) & 3 of
+     * block (j + 2) >> 2 -- words 0, 1 of block 0 belong to the emission */
+    int packed;
+    uint32_t words[4];
 } stream_t;
 
 static int draw(stream_t* s, double* u) {
     int j = s->n_draws;
-    if (s->use_philox) {
+    if (s->use_philox && s->packed) {
+        uint32_t block = ((uint32_t)j + 2u) >> 2;
+        if (!s->have_block || s->cur_block != block) {
+            block_words(s->id, block, s->atm, s->seed, s->words);
+            s->cur_block = block;
+            s->have_block = 1;
+        }
+        *u = u32mid(s->words[((uint32_t)j + 2u) & 3u]);
+    } else if (s->use_philox) {
         uint32_t block = (uint32_t)j >> 1;
         if (!s->have_block || s->cur_block != block) {
             block_uniforms(s->id, block, s->atm, s->seed, &s->ua, &s->ub);
@@ -426,7 +447,21 @@ int ora_run(const rt_params* p, int32_t n_wl, const double* wl, const double* g,
                     s.seed = p->seed;
                     s.atm = (uint32_t)atm;
                     consts_t c;
-                    emit_philox(p, &t, &s, &c);
+                    if (p->rng_mode == RT_RNG_PHILOX32X4) {
+                        /* wavelength from words 0, 1 of walk block 0 (52 bits); the direction draw, if any, is the
+                         * second uniform of emission block 0, as in the default mode */
+                        uint32_t w[4];
+                        double ua, ub;
+                        s.packed = 1;
+                        block_words(s.id, 0u, s.atm, s.seed, w);
+                        block_uniforms(s.id, EMIT_BLOCK, s.atm, s.seed, &ua, &ub);
+                        s.n_emit = 1;
+                        int k = t.mono_index >= 0 ? t.mono_index : sample_index(&t.alias, u52(w[0], w[1]));
+                        c.lam = wl[k]; c.g = g[k]; c.albedo = albedo[k]; c.scale = scale[k];
+                        c.mu0 = p->rand_mu ? ub : 1.0;
+                    } else {
+                        emit_philox(p, &t, &s, &c);
+                    }
                     walk_one(p, p->tau_atm[atm], &t, &s, c, &as, hist, dm_l, de_l,
                              (trace && atm == 0) ? trace + i : NULL);
                 }

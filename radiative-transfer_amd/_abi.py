@@ -11,11 +11,12 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "csrc", "librt_amd.so")
 
-RT_ABI_VERSION = 1
+RT_ABI_VERSION = 2
 
 BOUNDARY = {"reflect": 0, "absorb": 1, "reemit": 2}
 SCATTER = {"hg": 0, "iso": 1, "draine": 2}
 ORDER = {"mc": 0, "gray": 1}
+RNG = {"philox52": 0, "philox32x4": 1}
 
 FATE_ESCAPED, FATE_ESCAPED_UNCOUNTED, FATE_ABSORBED, FATE_BOUNDARY, FATE_GUARD = 1, 2, 3, 4, 5
 
@@ -38,6 +39,7 @@ class RtParams(C.Structure):
         ("seed", C.c_uint64), ("photon_id_base", C.c_uint64),
         ("monochromatic_wl", C.c_double), ("alpha", C.c_double), ("h", C.c_double),
         ("tau_atm", c_double_p), ("n_photons", c_u64_p),
+        ("rng_mode", C.c_int32), ("reserved_", C.c_int32),
     ]
 
 

@@ -73,6 +73,9 @@ __device__ __forceinline__ double u52(uint32_t a, uint32_t b) {
 // ---------------------------------------------------------------------------
 // Run configuration (wave-uniform; passed by value as a kernel argument).
 // ---------------------------------------------------------------------------
+// Uniform in (0,1) from one word: (w + 1/2) / 2^32, exact in fp64 (RT_RNG_PHILOX32X4).
+__device__ __forceinline__ double u32mid(uint32_t w) { return fma((double)w, 0x1p-32, 0x1p-33); }
+
 struct TableRec {  // one wavelength: what CreatePhotons copies into a photon row (MC code.py:403-408), with
                    // the two per-photon quotients GetZMomentum and HGScatter form on every call, 1/lambda and
                    // 1/(2*g) (MC code.py:367, :439), taken once on the host (IEEE division, as NumPy's)

@@ -177,7 +177,7 @@ __device__ __forceinline__ void store_chunk_wave(const AccWave& acc, const unsig
 //                 boundary, Henyey-Greenstein, no depth bins, abs_only off; integer tallies per wave.
 //   FAST = false  every boundary / scattering law / loop order, depth bins, re-emission, read from cfg.
 // Both give the same photon histories as one fly() + scatter() per photon per iteration (flight()).
-template <bool FAST>
+template <bool FAST, bool PACKED>
 __global__ __launch_bounds__(kWalkBlock) void walk_kernel(const Cfg cfg, const Sweep sw,
                                                            unsigned int* __restrict__ d_next,
                                                            double* __restrict__ d_chunk_sums,
@@ -250,10 +250,11 @@ __global__ __launch_bounds__(kWalkBlock) void walk_kernel(const Cfg cfg, const S
             bool flew = false;
             if (active) {
                 // ---- one Philox call: emission block for fresh lanes, scattering block otherwise ----
-                const uint32_t block = fresh ? kEmitBlock : src.blk;
+                // (PACKED: the photon's next block serves both, and the flight below as well)
+                const uint32_t block = PACKED ? src.blk : (fresh ? kEmitBlock : src.blk);
                 const PhiloxOut o = philox4x32_10(src.id_lo, src.id_hi, block, src.atm, src.k0, src.k1);
-                const double ua = u52(o.w0, o.w1);
-                const double ub = u52(o.w2, o.w3);
+                const double ua = (!PACKED || fresh) ? u52(o.w0, o.w1) : u32mid(o.w0);
+                double ub = PACKED ? u32mid(o.w1) : u52(o.w2, o.w3);
                 // alias entry of the new photons' bucket, requested now; scattering lanes read entry 0 (broadcast)
                 const double xb = ua * (double)cfg.n_wl;
                 int bucket = (int)xb;
@@ -272,7 +273,17 @@ __global__ __launch_bounds__(kWalkBlock) void walk_kernel(const Cfg cfg, const S
                 const TableRec rec = load_record(cfg, idx);
                 const bool guard = scatter_fate != 0 || (!fresh && ph.iter >= (uint32_t)cfg.max_events);
                 double u_step, u_abs;
-                src.pair(u_step, u_abs);
+                if (PACKED) {
+                    if (fresh) ++src.blk;
+                    u_step = u32mid(o.w2);
+                    u_abs = u32mid(o.w3);
+                    if (cfg.rand_mu && fresh) {  // the direction draw of a new photon: second uniform of emission block 0
+                        const PhiloxOut e = philox4x32_10(src.id_lo, src.id_hi, kEmitBlock, src.atm, src.k0, src.k1);
+                        ub = u52(e.w2, e.w3);
+                    }
+                } else {
+                    src.pair(u_step, u_abs);
+                }
                 if (fresh) {
                     set_constants(cfg, tau, rec, cfg.rand_mu ? ub : 1.0, ph);
                     start_photon(ph, acc);
@@ -509,22 +520,29 @@ size_t walk_lds_bytes(const Cfg& cfg, bool fast) {
            sizeof(uint32_t) * kWavesPerBlock * ((size_t)cfg.n_mu_bins + 1);
 }
 
-int walk_max_blocks_per_cu(bool fast, size_t lds_bytes) {
+int walk_max_blocks_per_cu(bool fast, bool packed, size_t lds_bytes) {
     int nb = 0;
-    hipError_t e = fast ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, walk_kernel<true>, kWalkBlock, lds_bytes)
-                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, walk_kernel<false>, kWalkBlock, lds_bytes);
+    hipError_t e =
+        fast ? (packed ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, walk_kernel<true, true>, kWalkBlock, lds_bytes)
+                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, walk_kernel<true, false>, kWalkBlock, lds_bytes))
+             : (packed ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, walk_kernel<false, true>, kWalkBlock, lds_bytes)
+                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, walk_kernel<false, false>, kWalkBlock, lds_bytes));
     if (e != hipSuccess || nb < 1) nb = 1;
     return nb;
 }
 
-hipError_t launch_walk(const Cfg& cfg, const Sweep& sw, bool fast, int grid, hipStream_t stream,
+hipError_t launch_walk(const Cfg& cfg, const Sweep& sw, bool fast, bool packed, int grid, hipStream_t stream,
                        unsigned int* d_next, double* d_chunk_sums, unsigned long long* d_counts,
                        unsigned long long* d_mu_hist, double* d_depth) {
     const size_t lds = walk_lds_bytes(cfg, fast);
-    if (fast)
-        walk_kernel<true><<<grid, kWalkBlock, lds, stream>>>(cfg, sw, d_next, d_chunk_sums, d_counts, d_mu_hist, d_depth);
+    if (fast && !packed)
+        walk_kernel<true, false><<<grid, kWalkBlock, lds, stream>>>(cfg, sw, d_next, d_chunk_sums, d_counts, d_mu_hist, d_depth);
+    else if (fast)
+        walk_kernel<true, true><<<grid, kWalkBlock, lds, stream>>>(cfg, sw, d_next, d_chunk_sums, d_counts, d_mu_hist, d_depth);
+    else if (!packed)
+        walk_kernel<false, false><<<grid, kWalkBlock, lds, stream>>>(cfg, sw, d_next, d_chunk_sums, d_counts, d_mu_hist, d_depth);
     else
-        walk_kernel<false><<<grid, kWalkBlock, lds, stream>>>(cfg, sw, d_next, d_chunk_sums, d_counts, d_mu_hist, d_depth);
+        walk_kernel<false, true><<<grid, kWalkBlock, lds, stream>>>(cfg, sw, d_next, d_chunk_sums, d_counts, d_mu_hist, d_depth);
     return hipGetLastError();
 }
 

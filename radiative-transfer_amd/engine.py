@@ -81,7 +81,11 @@ class SweepResult:
 
 def make_params(tau, n_photons, *, boundary="reflect", scatter="hg", order="mc", rand_mu=0, abs_only=0,
                 n_mu_bins=10, n_depth_bins=0, max_events=0, n_slabs=8, rank=0, world=1, seed=DEFAULT_SEED,
-                photon_id_base=0, monochromatic=0.0, alpha=0.3, h=H_PLANCK):
+                photon_id_base=0, monochromatic=0.0, alpha=0.3, h=H_PLANCK, rng="philox52"):
+    """rng: "philox52" (default; 52-bit uniforms, two Philox blocks per loop iteration) or "philox32x4" (one
+    block per iteration, 32-bit uniforms; faster, see rt_rng_mode in include/rt_amd.h)."""
+    if rng not in abi.RNG:
+        raise ValueError(f"rng must be one of {sorted(abi.RNG)}")
     if boundary not in abi.BOUNDARY:
         # the reference only prints this and carries on (MC code.py:571); here it is an error
         raise ValueError("No valid boundary condition specified, enter a boundary condition.")
@@ -92,7 +96,7 @@ def make_params(tau, n_photons, *, boundary="reflect", scatter="hg", order="mc",
     p = abi.RtParams(len(tau), abi.BOUNDARY[boundary], abi.SCATTER[scatter], abi.ORDER[order], int(rand_mu),
                      int(abs_only), int(n_mu_bins), int(n_depth_bins), int(max_events), int(n_slabs), int(rank),
                      int(world), int(seed), int(photon_id_base), float(monochromatic), float(alpha), float(h),
-                     _dp(tau), _u64p(npn))
+                     _dp(tau), _u64p(npn), abi.RNG[rng], 0)
     p._keep = (tau, npn)
     return p
 

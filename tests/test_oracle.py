@@ -171,3 +171,15 @@ def test_known_answer_emergent_intensity(c_oracle):
     got = intensity[np.argsort(-mids)]  # table runs from small theta (mu near 1) to large
     assert np.all(np.abs(np.degrees(np.arccos(np.sort(mids)[::-1])) - thetas) < 0.6)
     np.testing.assert_allclose(got, want, rtol=0.06)
+
+
+def test_packed_stream_of_the_oracle(c_oracle):
+    """RT_RNG_PHILOX32X4 in the oracle: same physics as the default stream (statistically) on a small sweep."""
+    wl = np.array([0.5]); g = np.array([0.6]); alb = np.array([0.7]); sc = np.array([1.0])
+    tau = np.array([0.1, 1.0, 5.0])
+    a = c_oracle.run(c_oracle.make_params(tau, 300000), wl, g, alb, sc, None)
+    b = c_oracle.run(c_oracle.make_params(tau, 300000, rng="philox32x4"), wl, g, alb, sc, None)
+    assert not np.array_equal(a.counts, b.counts)
+    fa = (a.sums[:, 0] - a.sums[:, 1] + a.sums[:, 2]) / a.sums[:, 0]
+    fb = (b.sums[:, 0] - b.sums[:, 1] + b.sums[:, 2]) / b.sums[:, 0]
+    np.testing.assert_allclose(fa, fb, rtol=0.03)
