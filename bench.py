@@ -45,7 +45,8 @@ def _cpu_atmosphere(task):
     rs = np.random.RandomState(12345 + k)
     cdf = np.cumsum(np.clip(np.nan_to_num(cfg["pdf"]), 0, 1))
     idx = np.minimum(np.searchsorted(cdf, rs.rand(n_cpu) * cdf[-1], side="right"), len(cdf) - 1)
-    r = nw.run_photons(cfg["tau_list"][k], cfg["wl"][idx], cfg["g"][idx], cfg["albedo"][idx], cfg["scale"][idx],
+    row = (lambda a: a if a.ndim == 1 else a[cfg["table_of_atm"][k]])  # several tables: this atmosphere's
+    r = nw.run_photons(cfg["tau_list"][k], cfg["wl"][idx], row(cfg["g"])[idx], row(cfg["albedo"])[idx], row(cfg["scale"])[idx],
                        np.ones(n_cpu), boundary=cfg["boundary"], scatter=cfg["scatter"], order=cfg["order"],
                        stream=nw.GlobalStream(rs), h=cfg["h"])
     return int(r["scatter_count"])
@@ -167,7 +168,8 @@ def main():
     def step(i):
         prm = rt.make_params(tau, total_photons, boundary=cfg["boundary"], scatter=cfg["scatter"], order=cfg["order"],
                              n_mu_bins=10, n_slabs=n_slabs, rank=rank, world=world, h=cfg["h"],
-                             monochromatic=cfg["monochromatic"], photon_id_base=i * total_photons, rng=args.rng)
+                             monochromatic=cfg["monochromatic"], photon_id_base=i * total_photons, rng=args.rng,
+                             table_of_atm=cfg.get("table_of_atm"))
         eng.run_device(prm, slab.data_ptr(), counts.data_ptr(), hist.data_ptr(), None, stream)
         if world > 1:
             # every slab entry is non-zero on exactly one rank, so the sum is exact and order-free

@@ -122,6 +122,7 @@ typedef struct rt_params {
     const uint64_t* n_photons;     /* [n_atm] photons per atmosphere (photon_reduction already applied) */
     int32_t rng_mode;              /* RT_RNG_* */
     int32_t reserved_;             /* 0 */
+    const int32_t* table_of_atm;   /* [n_atm] which table of rt_set_tables_multi an atmosphere uses; NULL = table 0 */
 } rt_params;
 
 /* Host-side result arrays of one sweep; any pointer may be NULL to skip it. */
@@ -164,6 +165,13 @@ int rt_device_info(rt_ctx* ctx, char* name, int name_len, int* n_cu, int* wave_s
  * n_wl == 1 gives gray / monochromatic dust. */
 int rt_set_tables(rt_ctx* ctx, int32_t n_wl, const double* wl, const double* g, const double* albedo,
                   const double* scale, const double* pdf);
+
+/* Several tables at once on one wavelength grid, e.g. one per grain species or size window, so that a sweep
+ * over (species x radius x optical depth) is ONE rt_run: g, albedo, scale, pdf are [n_tables][n_wl] (pdf may be
+ * NULL), wl is [n_wl].  Atmospheres pick their table with rt_params.table_of_atm.  rt_set_tables is the
+ * n_tables = 1 case. */
+int rt_set_tables_multi(rt_ctx* ctx, int32_t n_tables, int32_t n_wl, const double* wl, const double* g,
+                        const double* albedo, const double* scale, const double* pdf);
 
 /* The sweep: for every atmosphere a, walk n_photons[a] photons through a slab of optical depth
  * tau_atm[a] and return the tallies.  Replaces the loop body of runMC (MC code.py:1056-1062)

@@ -38,14 +38,18 @@ def _dp(a):
 
 def make_params(tau, n_photons, *, boundary="reflect", scatter="hg", order="mc", rand_mu=0, abs_only=0,
                 n_mu_bins=10, n_depth_bins=0, max_events=0, n_slabs=8, rank=0, world=1, seed=0x5EED2026,
-                photon_id_base=0, monochromatic=0.0, alpha=0.3, h=6.6261e-27, rng="philox52"):
+                photon_id_base=0, monochromatic=0.0, alpha=0.3, h=6.6261e-27, rng="philox52", table_of_atm=None):
     tau = np.ascontiguousarray(np.atleast_1d(tau), dtype=np.float64)
     npn = np.ascontiguousarray(np.broadcast_to(np.atleast_1d(n_photons), tau.shape), dtype=np.uint64)
     p = abi.RtParams(len(tau), abi.BOUNDARY[boundary], abi.SCATTER[scatter], abi.ORDER[order], int(rand_mu),
                      int(abs_only), int(n_mu_bins), int(n_depth_bins), int(max_events), int(n_slabs), int(rank),
                      int(world), int(seed), int(photon_id_base), float(monochromatic), float(alpha), float(h),
-                     _dp(tau), npn.ctypes.data_as(abi.c_u64_p), abi.RNG[rng], 0)
+                     _dp(tau), npn.ctypes.data_as(abi.c_u64_p), abi.RNG[rng], 0, None)
     p._keep = (tau, npn)
+    if table_of_atm is not None:
+        tab = np.ascontiguousarray(np.broadcast_to(np.atleast_1d(table_of_atm), tau.shape), dtype=np.int32)
+        p.table_of_atm = tab.ctypes.data_as(C.POINTER(C.c_int32))
+        p._keep = (tau, npn, tab)
     return p
 
 
@@ -79,11 +83,15 @@ def replay(params, xi, lam, g, albedo, scale, mu0):
 
 
 def run(params, wl, g, albedo, scale, pdf=None, trace=False):
-    arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in (wl, g, albedo, scale)]
-    pdf_a = None if pdf is None else np.ascontiguousarray(pdf, dtype=np.float64)
+    """2-D g / albedo / scale / pdf ([n_tables][n_wl]) are the tables params.table_of_atm indexes."""
+    wl_a = np.ascontiguousarray(wl, dtype=np.float64)
+    cols = [np.ascontiguousarray(np.atleast_2d(a), dtype=np.float64) for a in (g, albedo, scale)]
+    n_tables = cols[0].shape[0]
+    arrs = [wl_a] + cols
+    pdf_a = None if pdf is None else np.ascontiguousarray(np.broadcast_to(np.atleast_2d(pdf), cols[0].shape), dtype=np.float64)
     t = Tallies(params.n_atm, params.n_mu_bins, params.n_depth_bins, max(params.n_slabs, 1))
     tr = trace_array(int(params.n_photons[0])) if trace else None
-    rc = lib().ora_run(C.byref(params), C.c_int32(len(arrs[0])), *[_dp(a) for a in arrs],
+    rc = lib().ora_run(C.byref(params), C.c_int32(n_tables), C.c_int32(len(arrs[0])), *[_dp(a) for a in arrs],
                        None if pdf_a is None else _dp(pdf_a), C.byref(t.c),
                        None if tr is None else tr.ctypes.data_as(C.POINTER(abi.RtPhotonTrace)))
     assert rc == 0, rc

@@ -409,16 +409,23 @@ int ora_replay(const rt_params* p, int64_t n, int32_t max_draws, const double* x
 /* Production layout: Philox streams, table emission, slabs of this rank only
  * (see rt_run in rt_amd.h).  `trace`, if given, must hold n_photons[0] records and is
  * filled for atmosphere 0 only. */
-int ora_run(const rt_params* p, int32_t n_wl, const double* wl, const double* g, const double* albedo,
-            const double* scale, const double* pdf, rt_tallies* out, rt_photon_trace* trace) {
-    tables_t t;
-    t.n_wl = n_wl; t.wl = wl; t.g = g; t.albedo = albedo; t.scale = scale; t.mono_index = -1;
-    if (!build_alias(n_wl, pdf, &t.alias)) { free_alias(&t.alias); return RT_ERR_INVALID; }
+int ora_run(const rt_params* p, int32_t n_tables, int32_t n_wl, const double* wl, const double* g_all,
+            const double* albedo_all, const double* scale_all, const double* pdf_all, rt_tallies* out,
+            rt_photon_trace* trace) {
+    /* g_all, albedo_all, scale_all, pdf_all: [n_tables][n_wl]; atmosphere a walks table p->table_of_atm[a] */
+    tables_t* tabs = (tables_t*)calloc((size_t)n_tables, sizeof(tables_t));
+    int mono = -1;
     if (p->monochromatic_wl != 0) {
         double want = round(p->monochromatic_wl * 1e4) / 1e4;
         for (int i = 0; i < n_wl; ++i)
-            if (wl[i] == want || wl[i] == p->monochromatic_wl) { t.mono_index = i; break; }
-        if (t.mono_index < 0) { free_alias(&t.alias); return RT_ERR_INVALID; }
+            if (wl[i] == want || wl[i] == p->monochromatic_wl) { mono = i; break; }
+        if (mono < 0) { free(tabs); return RT_ERR_INVALID; }
+    }
+    for (int k = 0; k < n_tables; ++k) {
+        tables_t* tk = &tabs[k];
+        tk->n_wl = n_wl; tk->wl = wl; tk->g = g_all + (size_t)k * n_wl; tk->albedo = albedo_all + (size_t)k * n_wl;
+        tk->scale = scale_all + (size_t)k * n_wl; tk->mono_index = mono;
+        if (!build_alias(n_wl, pdf_all ? pdf_all + (size_t)k * n_wl : NULL, &tk->alias)) return RT_ERR_INVALID;
     }
     const int n_slabs = p->n_slabs > 0 ? p->n_slabs : 8;
     const int world = p->world > 0 ? p->world : 1;
@@ -426,6 +433,10 @@ int ora_run(const rt_params* p, int32_t n_wl, const double* wl, const double* g,
     for (int atm = 0; atm < p->n_atm; ++atm) {
         acc_t a;
         memset(&a, 0, sizeof a);
+        const int which = p->table_of_atm ? p->table_of_atm[atm] : 0;
+        if (which < 0 || which >= n_tables) return RT_ERR_INVALID;
+        const tables_t t = tabs[which];
+        const double *g = t.g, *albedo = t.albedo, *scale = t.scale;
         uint64_t N = p->n_photons[atm];
         uint64_t L = (N + (uint64_t)n_slabs - 1) / (uint64_t)n_slabs;
         uint64_t* hist = out->mu_hist ? out->mu_hist + (size_t)atm * ((size_t)p->n_mu_bins + 1) : NULL;
@@ -478,6 +489,7 @@ int ora_run(const rt_params* p, int32_t n_wl, const double* wl, const double* g,
         if (de) memcpy(de, de_l, sizeof(double) * (size_t)nd);
         free(dm_l); free(de_l);
     }
-    free_alias(&t.alias);
+    for (int k = 0; k < n_tables; ++k) free_alias(&tabs[k].alias);
+    free(tabs);
     return 0;
 }

@@ -39,7 +39,7 @@ class RtParams(C.Structure):
         ("seed", C.c_uint64), ("photon_id_base", C.c_uint64),
         ("monochromatic_wl", C.c_double), ("alpha", C.c_double), ("h", C.c_double),
         ("tau_atm", c_double_p), ("n_photons", c_u64_p),
-        ("rng_mode", C.c_int32), ("reserved_", C.c_int32),
+        ("rng_mode", C.c_int32), ("reserved_", C.c_int32), ("table_of_atm", C.POINTER(C.c_int32)),
     ]
 
 
@@ -95,7 +95,7 @@ class RtPhotonTrace(C.Structure):
 
 EXPORTS = ["rt_abi_version", "rt_last_error", "rt_create", "rt_destroy", "rt_device_info", "rt_set_tables",
            "rt_run", "rt_run_device", "rt_replay", "rt_kernel_time", "rt_selftest_math", "rt_build_grain_tables",
-           "rt_shell_velocity", "rt_shell_rhs"]
+           "rt_shell_velocity", "rt_shell_rhs", "rt_set_tables_multi"]
 
 _lib = None
 
@@ -117,6 +117,7 @@ def load_library(path=None):
     lib.rt_destroy.argtypes = [vp]
     lib.rt_device_info.argtypes = [vp, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.rt_set_tables.argtypes = [vp, C.c_int32, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p]
+    lib.rt_set_tables_multi.argtypes = [vp, C.c_int32, C.c_int32, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p]
     lib.rt_run.argtypes = [vp, C.POINTER(RtParams), C.POINTER(RtTallies)]
     lib.rt_run_device.argtypes = [vp, C.POINTER(RtParams), vp, vp, vp, vp, vp]
     lib.rt_replay.argtypes = [vp, C.POINTER(RtParams), C.c_int64, C.c_int32, c_double_p, c_double_p, c_double_p,

@@ -67,6 +67,7 @@ struct rt_ctx {
     hipStream_t stream = nullptr;
     // tables
     int32_t n_wl = 0;
+    int32_t n_tables = 0;
     std::vector<double> wl;
     DevBuf<rt::TableRec> d_rec;
     DevBuf<rt::AliasEntry> d_alias;
@@ -269,55 +270,68 @@ int rt_device_info(rt_ctx* ctx, char* name, int name_len, int* n_cu, int* wave_s
     return RT_OK;
 }
 
-int rt_set_tables(rt_ctx* ctx, int32_t n_wl, const double* wl, const double* g, const double* albedo,
-                  const double* scale, const double* pdf) {
+int rt_set_tables_multi(rt_ctx* ctx, int32_t n_tables, int32_t n_wl, const double* wl, const double* g,
+                        const double* albedo, const double* scale, const double* pdf) {
     if (!ctx) return fail(RT_ERR_INVALID, "ctx is NULL");
-    if (n_wl < 1 || !wl || !g || !albedo || !scale) return fail(RT_ERR_INVALID, "empty or NULL table");
+    if (n_tables < 1 || n_wl < 1 || !wl || !g || !albedo || !scale) return fail(RT_ERR_INVALID, "empty or NULL table");
     if (n_wl > (1 << 24)) return fail(RT_ERR_LIMIT, "n_wl %d exceeds 2^24", n_wl);
+    if ((long long)n_tables * n_wl > (1ll << 28)) return fail(RT_ERR_LIMIT, "n_tables * n_wl exceeds 2^28");
     RT_HIP(hipSetDevice(ctx->device));
-    std::vector<rt::TableRec> rec((size_t)n_wl);
-    std::vector<double> w((size_t)n_wl);
-    double total = 0.0;
-    for (int i = 0; i < n_wl; ++i) {
-        rec[i] = {wl[i], g[i], albedo[i], scale[i], 1.0 / wl[i], 1.0 / (2.0 * g[i])};
-        double p = pdf ? pdf[i] : 1.0;
-        if (!(p > 0.0)) p = 0.0;  // also maps NaN to 0
-        if (p > 1.0) p = 1.0;     // AcceptReject accepts with probability min(PDF, 1)
-        w[i] = p;
-        total += p;
-    }
-    if (!(total > 0.0)) return fail(RT_ERR_INVALID, "emission law has no positive weight");
-    // Alias table (Vose).  The construction order is part of the definition of the photon streams:
-    // q_i = (w_i * n) / total; wavelengths with q < 1 ("small") and q >= 1 ("large") are kept on two
-    // stacks filled in ascending index order; pop one of each, the small one keeps q and points to the
-    // large one, whose excess (q_l + q_s) - 1 decides on which stack it goes back.
-    std::vector<rt::AliasEntry> alias((size_t)n_wl);
-    std::vector<double> q((size_t)n_wl);
+    const size_t n = (size_t)n_wl, total_n = n * (size_t)n_tables;
+    std::vector<rt::TableRec> rec(total_n);
+    std::vector<rt::AliasEntry> alias(total_n);
+    std::vector<double> w(n), q(n);
     std::vector<int32_t> small, large;
-    small.reserve((size_t)n_wl);
-    large.reserve((size_t)n_wl);
-    for (int i = 0; i < n_wl; ++i) {
-        q[i] = (w[i] * (double)n_wl) / total;
-        (q[i] < 1.0 ? small : large).push_back(i);
+    small.reserve(n);
+    large.reserve(n);
+    for (int t = 0; t < n_tables; ++t) {
+        const size_t o = (size_t)t * n;
+        double total = 0.0;
+        for (int i = 0; i < n_wl; ++i) {
+            rec[o + i] = {wl[i], g[o + i], albedo[o + i], scale[o + i], 1.0 / wl[i], 1.0 / (2.0 * g[o + i])};
+            double p = pdf ? pdf[o + i] : 1.0;
+            if (!(p > 0.0)) p = 0.0;  // also maps NaN to 0
+            if (p > 1.0) p = 1.0;     // AcceptReject accepts with probability min(PDF, 1)
+            w[i] = p;
+            total += p;
+        }
+        if (!(total > 0.0)) return fail(RT_ERR_INVALID, "emission law of table %d has no positive weight", t);
+        // Alias table (Vose).  The construction order is part of the definition of the photon streams:
+        // q_i = (w_i * n) / total; wavelengths with q < 1 ("small") and q >= 1 ("large") are kept on two
+        // stacks filled in ascending index order; pop one of each, the small one keeps q and points to the
+        // large one, whose excess (q_l + q_s) - 1 decides on which stack it goes back.
+        small.clear();
+        large.clear();
+        for (int i = 0; i < n_wl; ++i) {
+            q[i] = (w[i] * (double)n_wl) / total;
+            (q[i] < 1.0 ? small : large).push_back(i);
+        }
+        rt::AliasEntry* al = alias.data() + o;
+        while (!small.empty() && !large.empty()) {
+            const int32_t s = small.back(), l = large.back();
+            small.pop_back();
+            large.pop_back();
+            al[s] = {q[s], l, 0};
+            q[l] = (q[l] + q[s]) - 1.0;
+            (q[l] < 1.0 ? small : large).push_back(l);
+        }
+        for (int32_t i : large) al[i] = {1.0, i, 0};
+        for (int32_t i : small) al[i] = {1.0, i, 0};  // only reachable through rounding; q is 1 to within an ulp
     }
-    while (!small.empty() && !large.empty()) {
-        const int32_t s = small.back(), l = large.back();
-        small.pop_back();
-        large.pop_back();
-        alias[s] = {q[s], l, 0};
-        q[l] = (q[l] + q[s]) - 1.0;
-        (q[l] < 1.0 ? small : large).push_back(l);
-    }
-    for (int32_t i : large) alias[i] = {1.0, i, 0};
-    for (int32_t i : small) alias[i] = {1.0, i, 0};  // only reachable through rounding; q is 1 to within an ulp
-    RT_HIP(ctx->d_rec.reserve((size_t)n_wl));
-    RT_HIP(ctx->d_alias.reserve((size_t)n_wl));
+    RT_HIP(ctx->d_rec.reserve(total_n));
+    RT_HIP(ctx->d_alias.reserve(total_n));
     RT_HIP(hipStreamSynchronize(ctx->stream));
-    RT_HIP(hipMemcpy(ctx->d_rec.p, rec.data(), sizeof(rt::TableRec) * (size_t)n_wl, hipMemcpyHostToDevice));
-    RT_HIP(hipMemcpy(ctx->d_alias.p, alias.data(), sizeof(rt::AliasEntry) * (size_t)n_wl, hipMemcpyHostToDevice));
+    RT_HIP(hipMemcpy(ctx->d_rec.p, rec.data(), sizeof(rt::TableRec) * total_n, hipMemcpyHostToDevice));
+    RT_HIP(hipMemcpy(ctx->d_alias.p, alias.data(), sizeof(rt::AliasEntry) * total_n, hipMemcpyHostToDevice));
     ctx->n_wl = n_wl;
+    ctx->n_tables = n_tables;
     ctx->wl.assign(wl, wl + n_wl);
     return RT_OK;
+}
+
+int rt_set_tables(rt_ctx* ctx, int32_t n_wl, const double* wl, const double* g, const double* albedo,
+                  const double* scale, const double* pdf) {
+    return rt_set_tables_multi(ctx, 1, n_wl, wl, g, albedo, scale, pdf);
 }
 
 int rt_run_device(rt_ctx* ctx, const rt_params* p, void* d_slab_sums, void* d_counts, void* d_mu_hist, void* d_depth,
@@ -326,6 +340,10 @@ int rt_run_device(rt_ctx* ctx, const rt_params* p, void* d_slab_sums, void* d_co
     int rc = check_common(p);
     if (rc) return rc;
     if (ctx->n_wl < 1) return fail(RT_ERR_STATE, "rt_set_tables must be called before rt_run");
+    if (p->table_of_atm)
+        for (int a = 0; a < p->n_atm; ++a)
+            if (p->table_of_atm[a] < 0 || p->table_of_atm[a] >= ctx->n_tables)
+                return fail(RT_ERR_INVALID, "atmosphere %d asks for table %d of %d", a, p->table_of_atm[a], ctx->n_tables);
     if (!d_slab_sums || !d_counts || !d_mu_hist) return fail(RT_ERR_INVALID, "device result buffer is NULL");
     if (p->n_depth_bins > 0 && !d_depth) return fail(RT_ERR_INVALID, "d_depth is NULL but n_depth_bins > 0");
     const int n_slabs = p->n_slabs > 0 ? p->n_slabs : 8;
@@ -383,6 +401,8 @@ int rt_run_device(rt_ctx* ctx, const rt_params* p, void* d_slab_sums, void* d_co
         pl.n_photons = p->n_photons[a];
         pl.slab_len = (pl.n_photons + (unsigned long long)n_slabs - 1) / (unsigned long long)n_slabs;
         pl.atm = (uint32_t)a;
+        pl.table = p->table_of_atm ? (uint32_t)p->table_of_atm[a] : 0u;
+        pl.pad_ = 0u;
         pl.chunk = chunk_for(pl.n_photons);
         pl.chunks_per_slab = (uint32_t)((pl.slab_len + pl.chunk - 1) / pl.chunk);
         if (pl.chunks_per_slab == 0) pl.chunks_per_slab = 1;

@@ -103,6 +103,7 @@ struct Cfg {
     const TableRec* rec;
     const AliasEntry* alias;  // n_wl entries
     int32_t n_wl, mono_index;
+    int32_t table_base;  // first entry of the current atmosphere's table in rec / alias (several tables back to back)
     const LogTableEntry* log_table;  // kLogTableEntries entries in global memory (copied to LDS per workgroup)
 };
 
@@ -200,25 +201,17 @@ struct ReplaySrc {
 // Emission: wavelength index from the tabulated law, then the photon constants.
 // P(index i) is proportional to min(max(pdf_i,0),1)  (AcceptReject, MC code.py:239-268).
 // ---------------------------------------------------------------------------
-// u in [0,1) -> wavelength index with P(i) proportional to the table weights:
+// u in [0,1) -> record index (table_base + wavelength index) with P(i) proportional to the table weights:
 // x = u*n, bucket = floor(x), keep the bucket's own wavelength if frac(x) < prob, else its alias.
 __device__ __forceinline__ int sample_index(const Cfg& cfg, double u) {
-    if (cfg.mono_index >= 0) return cfg.mono_index;
+    if (cfg.mono_index >= 0) return cfg.table_base + cfg.mono_index;
     const double x = u * (double)cfg.n_wl;
     int i = (int)x;
     i = i < cfg.n_wl ? i : cfg.n_wl - 1;  // u*n can round up to n for u just below 1
     const double frac = x - (double)i;
-#ifdef RT_ABLATE_ALIAS
-    return frac < 0.5 ? i : (i ^ 1);
-#elif defined(RT_ABLATE_ALIAS_NODEP)
-    const uint4 raw = *reinterpret_cast<const uint4*>(&cfg.alias[i]);  // loaded but not waited for here
-    asm volatile("" ::"v"(raw.x), "v"(raw.z));
-    return frac < 0.5 ? i : (i ^ 1);
-#else
-    const uint4 raw = *reinterpret_cast<const uint4*>(&cfg.alias[i]);  // one 16-byte load
+    const uint4 raw = *reinterpret_cast<const uint4*>(&cfg.alias[cfg.table_base + i]);  // one 16-byte load
     const double prob = __hiloint2double((int)raw.y, (int)raw.x);
-    return frac < prob ? i : (int)raw.z;
-#endif
+    return cfg.table_base + (frac < prob ? i : (int)raw.z);
 }
 
 // Per-photon constants from the photon's row values.  1/lambda, 1/(2*g), 1+g**2 and 1-g**2 are the

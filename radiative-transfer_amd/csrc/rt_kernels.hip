@@ -94,6 +94,7 @@ struct WorkItem {
     unsigned long long cursor, end;  // photon ids [cursor, end) before id_base is added
     double tau;
     uint32_t atm;
+    uint32_t table;
     size_t slot;  // where this chunk's partial sums go
 };
 
@@ -125,6 +126,7 @@ __device__ __forceinline__ bool pop_item(const Sweep& sw, unsigned int* d_next, 
     it.end = uniform64(e < slab_hi ? e : slab_hi);
     it.tau = __longlong_as_double((long long)uniform64((unsigned long long)__double_as_longlong(plan.tau)));
     it.atm = __builtin_amdgcn_readfirstlane(plan.atm);
+    it.table = __builtin_amdgcn_readfirstlane(plan.table);
     it.slot = (size_t)uniform64((unsigned long long)plan.slot_base + (unsigned long long)j * plan.chunks_per_slab + c);
     return true;
 }
@@ -178,7 +180,7 @@ __device__ __forceinline__ void store_chunk_wave(const AccWave& acc, const unsig
 //   FAST = false  every boundary / scattering law / loop order, depth bins, re-emission, read from cfg.
 // Both give the same photon histories as one fly() + scatter() per photon per iteration (flight()).
 template <bool FAST, bool PACKED>
-__global__ __launch_bounds__(kWalkBlock) void walk_kernel(const Cfg cfg, const Sweep sw,
+__global__ __launch_bounds__(kWalkBlock) void walk_kernel(const Cfg cfg0, const Sweep sw,
                                                            unsigned int* __restrict__ d_next,
                                                            double* __restrict__ d_chunk_sums,
                                                            unsigned long long* __restrict__ d_counts,
@@ -187,15 +189,17 @@ __global__ __launch_bounds__(kWalkBlock) void walk_kernel(const Cfg cfg, const S
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int nmu = cfg.n_mu_bins + 1;
-    const int nd = FAST ? 0 : cfg.n_depth_bins;
+    const int nmu = cfg0.n_mu_bins + 1;
+    const int nd = FAST ? 0 : cfg0.n_depth_bins;
     const Hist hist = wave_hist(lds_raw, wave, nmu, nd);
-    stage_log_table(cfg, lds_raw);
+    stage_log_table(cfg0, lds_raw);
     clear_hist(hist, lane, nmu, nd);
 
     WorkItem it;
     while (pop_item(sw, d_next, lane, it)) {
         const double tau = it.tau;
+        Cfg cfg = cfg0;  // this atmosphere's table (wave-uniform)
+        cfg.table_base = (int32_t)(it.table * (uint32_t)cfg0.n_wl);
         typename std::conditional<FAST, AccWave, Acc>::type acc;
         acc.clear();
         unsigned long long wc[RT_NCNT] = {};  // FAST: wave totals, the same value in every lane
@@ -260,7 +264,7 @@ __global__ __launch_bounds__(kWalkBlock) void walk_kernel(const Cfg cfg, const S
                 int bucket = (int)xb;
                 bucket = bucket < cfg.n_wl ? bucket : cfg.n_wl - 1;
                 bucket = fresh ? bucket : 0;
-                const uint4 raw = *reinterpret_cast<const uint4*>(&cfg.alias[bucket]);
+                const uint4 raw = *reinterpret_cast<const uint4*>(&cfg.alias[cfg.table_base + bucket]);
                 int scatter_fate = 0;
                 if (!fresh) {
                     ++src.blk;
@@ -269,7 +273,7 @@ __global__ __launch_bounds__(kWalkBlock) void walk_kernel(const Cfg cfg, const S
                 const double prob = __hiloint2double((int)raw.y, (int)raw.x);
                 int idx = (xb - (double)bucket) < prob ? bucket : (int)raw.z;
                 idx = cfg.mono_index >= 0 ? cfg.mono_index : idx;
-                idx = fresh ? idx : 0;
+                idx = fresh ? cfg.table_base + idx : 0;
                 const TableRec rec = load_record(cfg, idx);
                 const bool guard = scatter_fate != 0 || (!fresh && ph.iter >= (uint32_t)cfg.max_events);
                 double u_step, u_abs;

@@ -19,6 +19,8 @@ struct AtmPlan {
     uint32_t chunk;            // photon ids per chunk
     uint32_t chunks_per_slab;  // ceil(slab_len / chunk)
     uint32_t slot_base;        // first chunk-partial slot of this atmosphere
+    uint32_t table;            // which of the context's tables this atmosphere uses
+    uint32_t pad_;
 };
 
 struct Sweep {

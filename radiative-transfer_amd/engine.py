@@ -81,7 +81,7 @@ class SweepResult:
 
 def make_params(tau, n_photons, *, boundary="reflect", scatter="hg", order="mc", rand_mu=0, abs_only=0,
                 n_mu_bins=10, n_depth_bins=0, max_events=0, n_slabs=8, rank=0, world=1, seed=DEFAULT_SEED,
-                photon_id_base=0, monochromatic=0.0, alpha=0.3, h=H_PLANCK, rng="philox52"):
+                photon_id_base=0, monochromatic=0.0, alpha=0.3, h=H_PLANCK, rng="philox52", table_of_atm=None):
     """rng: "philox52" (default; 52-bit uniforms, two Philox blocks per loop iteration) or "philox32x4" (one
     block per iteration, 32-bit uniforms; faster, see rt_rng_mode in include/rt_amd.h)."""
     if rng not in abi.RNG:
@@ -96,8 +96,12 @@ def make_params(tau, n_photons, *, boundary="reflect", scatter="hg", order="mc",
     p = abi.RtParams(len(tau), abi.BOUNDARY[boundary], abi.SCATTER[scatter], abi.ORDER[order], int(rand_mu),
                      int(abs_only), int(n_mu_bins), int(n_depth_bins), int(max_events), int(n_slabs), int(rank),
                      int(world), int(seed), int(photon_id_base), float(monochromatic), float(alpha), float(h),
-                     _dp(tau), _u64p(npn), abi.RNG[rng], 0)
+                     _dp(tau), _u64p(npn), abi.RNG[rng], 0, None)
     p._keep = (tau, npn)
+    if table_of_atm is not None:  # which of the tables given to Engine.set_tables (2-D columns) each atmosphere uses
+        tab = np.ascontiguousarray(np.broadcast_to(np.atleast_1d(table_of_atm), tau.shape), dtype=np.int32)
+        p.table_of_atm = tab.ctypes.data_as(C.POINTER(C.c_int32))
+        p._keep = (tau, npn, tab)
     return p
 
 
@@ -132,18 +136,21 @@ class Engine:
         return dict(name=name.value.decode(), compute_units=cu.value, wave_size=ws.value, clock_khz=clk.value)
 
     def set_tables(self, wl, g, albedo, scale, pdf=None):
-        arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in (wl, g, albedo, scale)]
-        n = len(arrs[0])
-        if any(len(a) != n for a in arrs):
+        """Columns of Grain_data on the wavelength grid `wl`.  2-D columns [n_tables][n_wl] load several tables
+        (species, size windows ...) at once; make_params(table_of_atm=...) says which atmosphere uses which."""
+        wl_a = np.ascontiguousarray(wl, dtype=np.float64)
+        cols = [np.ascontiguousarray(np.atleast_2d(a), dtype=np.float64) for a in (g, albedo, scale)]
+        n = len(wl_a)
+        n_tables = cols[0].shape[0]
+        if any(c.shape != (n_tables, n) for c in cols):
             raise ValueError("table columns differ in length")
         pdf_a = None
         if pdf is not None:
-            pdf_a = np.ascontiguousarray(pdf, dtype=np.float64)
-            if len(pdf_a) != n:
-                raise ValueError("pdf length differs from the table")
-        self._check(self._lib.rt_set_tables(self._ctx, n, *[_dp(a) for a in arrs],
-                                            None if pdf_a is None else _dp(pdf_a)))
+            pdf_a = np.ascontiguousarray(np.broadcast_to(np.atleast_2d(pdf), (n_tables, n)), dtype=np.float64)
+        self._check(self._lib.rt_set_tables_multi(self._ctx, n_tables, n, _dp(wl_a), *[_dp(c) for c in cols],
+                                                  None if pdf_a is None else _dp(pdf_a)))
         self.n_wl = n
+        self.n_tables = n_tables
 
     def run(self, params):
         n_slabs = params.n_slabs if params.n_slabs > 0 else 8

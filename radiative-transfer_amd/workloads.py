@@ -57,8 +57,27 @@ def five_species_1e9(wl_list=None, grain_mix=(0.2, 0.2, 0.2, 0.2, 0.2)):
                    describe="Sil/Gra/SiC/SUV/PAH equal mix, Planck(3e4 K) emission, reflect + hg")
 
 
+def species_radius_batch(wl_list=None, radii_pc=(5, 10, 20, 50, 100), total_histories=10 ** 10):
+    """Config 5: 5 shell radii x {Sil, Gra, SiC, mix} x 100 optical depths as ONE sweep of 2000 atmospheres over
+    four grain tables (set_tables with 2-D columns + table_of_atm); 1e10 photon histories split evenly.  The
+    radius only enters the conversion tau -> column density afterwards (tau_to_radius), so each radius repeats
+    the tau list; the atmosphere index still gives every atmosphere its own random streams."""
+    kinds = ["Sil", "Gra", "SiC", "mix"]
+    grains = [tables.grain_data(k, 0.001, 1, wl_list) for k in kinds]
+    out = _finish("species_radius_batch", grains[0], np.tile(TAU_LIST_MC, len(radii_pc) * len(kinds)), 1,
+                  describe="5 radii x {Sil, Gra, SiC, mix} x 100 optical depths in one sweep, Planck(3e4 K) emission, reflect + hg")
+    for key, col in (("g", "g"), ("albedo", "Albedo"), ("scale", "Scale")):
+        out[key] = np.stack([np.asarray(gr[col], dtype=float) for gr in grains])
+    n_atm = len(out["tau_list"])
+    out["table_of_atm"] = np.tile(np.repeat(np.arange(len(kinds)), len(TAU_LIST_MC)), len(radii_pc)).astype(np.int32)
+    out["radius_of_atm"] = np.repeat(np.asarray(radii_pc, dtype=float), len(kinds) * len(TAU_LIST_MC))
+    out["n_photons"] = int(total_histories // n_atm)
+    out["h_g"] = None
+    return out
+
+
 WORKLOADS = {"gray_1e5": gray_1e5, "sil_single_1e6": sil_single_1e6, "mix_2e7": mix_2e7,
-             "five_species_1e9": five_species_1e9}
+             "five_species_1e9": five_species_1e9, "species_radius_batch": species_radius_batch}
 
 
 def tau_to_radius(tau, sigma_g, kappa_rp_ref, h_g, f_dg=1 / 100):
