@@ -43,7 +43,8 @@ def _cpu_atmosphere(task):
     k, n_cpu = task
     cfg = _CPU_CFG
     rs = np.random.RandomState(12345 + k)
-    cdf = np.cumsum(np.clip(np.nan_to_num(cfg["pdf"]), 0, 1))
+    pdf = np.ones(len(cfg["wl"])) if cfg["pdf"] is None else cfg["pdf"]
+    cdf = np.cumsum(np.clip(np.nan_to_num(pdf), 0, 1))
     idx = np.minimum(np.searchsorted(cdf, rs.rand(n_cpu) * cdf[-1], side="right"), len(cdf) - 1)
     row = (lambda a: a if a.ndim == 1 else a[cfg["table_of_atm"][k]])  # several tables: this atmosphere's
     r = nw.run_photons(cfg["tau_list"][k], cfg["wl"][idx], row(cfg["g"])[idx], row(cfg["albedo"])[idx], row(cfg["scale"])[idx],
