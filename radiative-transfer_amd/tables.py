@@ -199,6 +199,37 @@ def get_tau_scaling(gs, grain_min, grain_max, wl_list, wl_ref=0.656, sed=None):
                 ExtScale=k["Kappa_F"] / k["Kappa_F"][index], kappa_av_RP=k["kappa_av_RP"], kappa_av_F=k["kappa_av_F"])
 
 
+def l_edd_dataframe(spectra, wl_list, grain_min=0.001, grain_max=1, f_dg=1 / 100, species=("Sil", "SiC", "Gra"),
+                    mass=None, folders=None, engine=None):
+    """The table GetLEddDataFrame builds (read_BPASS.py:207-253): for every age column of a spectra table the
+    summed luminosity and, per species, the luminosity-weighted opacities <kappa_RP>, <kappa_F> and
+    L_Edd = 1.299e4 / (<kappa_RP> f_dg).
+
+    spectra: mapping {log age: L_lambda on wl_list} (the BPASS frame without its WL column).  The reference calls
+    GetKappas once per (age, species) -- 51 x 3 times, each re-reading every grain file; the grain-size integrals
+    do not depend on the spectrum, so here kappa(lambda) is formed once per species (on the GPU if `engine` is
+    given) and every age is one wavelength integral of it."""
+    wl_list = np.asarray(wl_list, dtype=float)
+    ages = sorted(spectra, key=float)
+    lum = np.stack([np.asarray(spectra[a], dtype=float) for a in ages])          # [n_age][n_wl]
+    total = lum.sum(axis=1)
+    out = {"time": np.array([float(a) for a in ages]), "time exp": np.power(10, np.array([float(a) for a in ages])),
+           "L_bol_BPASS": total}
+    folders = folders or {}
+    for sp in species:
+        gs = load_species(sp, folders.get(sp))
+        k = grain_tables_device(engine, gs, grain_min, grain_max, wl_list) if engine is not None \
+            else get_kappas(gs, grain_min, grain_max, wl_list)
+        av_rp = _trapz(k["Kappa_RP"][None, :] * lum, x=wl_list, axis=1) * 10 ** 4 / total
+        av_f = _trapz(k["Kappa_F"][None, :] * lum, x=wl_list, axis=1) * 10 ** 4 / total
+        out[f"kappa_av_RP_{sp}"] = av_rp
+        out[f"kappa_av_F_{sp}"] = av_f
+        out[f"L_Edd_{sp}"] = 1.299 * 10 ** 4 / (av_rp * f_dg)   # read_BPASS.py:225
+    if mass is not None:
+        out["Mass"] = np.asarray(mass, dtype=float)
+    return out
+
+
 # --------------------------------------------------------------------------------------
 # GetDraineAverage (the recipe behind the '<species> Average Values.csv' files)
 # --------------------------------------------------------------------------------------

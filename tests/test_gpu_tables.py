@@ -76,3 +76,12 @@ def test_rejects_bad_input(engine):
     rt = importlib.import_module("radiative-transfer_amd")
     with pytest.raises(rt.RtError):
         tables.grain_tables_device(engine, gs, 500.0, 600.0, np.array([0.5, 0.6]))
+
+
+def test_l_edd_dataframe_on_device(engine):
+    wl = tables.reference_wavelength_grid()[::10]
+    spectra = {"6.0": tables.planck_sed(wl, 4.0e4), "6.5": tables.planck_sed(wl, 3.0e4), "9.0": tables.planck_sed(wl, 5.0e3)}
+    host = tables.l_edd_dataframe(spectra, wl)
+    dev = tables.l_edd_dataframe(spectra, wl, engine=engine)
+    for key in host:
+        _close(dev[key], host[key], 1e-12)

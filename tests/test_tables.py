@@ -114,3 +114,19 @@ def test_join_on_wavelength():
     key, g, alb, sc = tables.join_on_wavelength([0.30000000000000004, 0.1, 0.25], grain)
     assert list(key) == [0.3, 0.1, 0.25]
     assert g[0] == 3 and g[1] == 1 and np.isnan(g[2]) and np.isnan(sc[2])
+
+
+def test_l_edd_dataframe_matches_per_age_get_kappas():
+    """One kappa(lambda) per species + one wavelength integral per age = GetKappas called per (age, species)."""
+    wl = tables.reference_wavelength_grid()[::25]
+    spectra = {"6.0": tables.planck_sed(wl, 4.0e4), "7.0": tables.planck_sed(wl, 2.0e4), "8.5": tables.planck_sed(wl, 6.0e3)}
+    df = tables.l_edd_dataframe(spectra, wl, 0.001, 1)
+    assert list(df["time"]) == [6.0, 7.0, 8.5] and np.allclose(df["time exp"], [1e6, 1e7, 10 ** 8.5])
+    for sp in ("Sil", "SiC", "Gra"):
+        gs = tables.load_species(sp)
+        for i, age in enumerate(("6.0", "7.0", "8.5")):
+            k = tables.get_kappas(gs, 0.001, 1, wl, spectra[age])
+            assert df[f"kappa_av_RP_{sp}"][i] == pytest.approx(k["kappa_av_RP"], rel=1e-12)
+            assert df[f"kappa_av_F_{sp}"][i] == pytest.approx(k["kappa_av_F"], rel=1e-12)
+            assert df["L_bol_BPASS"][i] == pytest.approx(k["L"], rel=1e-14)
+        assert np.allclose(df[f"L_Edd_{sp}"], 1.299e4 / (df[f"kappa_av_RP_{sp}"] * 0.01), rtol=1e-15)
