@@ -141,7 +141,8 @@ __global__ void shell_ode_kernel(const ShellModel m, const ShellRegions rg, cons
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rg.n) return;
     const Region q = load_region(rg, i);
-    const double r0 = q.h_g_i, r_end = rg.r_end[i];
+    // beyond r_escape the reference sets dv/dr = -inf and its solver stops (MC code.py:951-953): integrate to there
+    const double r0 = q.h_g_i, r_end = rg.r_end[i], r_stop = fmin(r_end, m.r_escape);
     double r = r0, v = ct.v0, t = ct.t0;
     double v_max = v, r_vmax = r, t_vmax = t;
     int status = RT_SHELL_REACHED_END, steps = 0, next_out = 0;
@@ -152,7 +153,7 @@ __global__ void shell_ode_kernel(const ShellModel m, const ShellRegions rg, cons
         out.v_out[(size_t)i * ct.n_out + k] = __builtin_nan("");
         out.t_out[(size_t)i * ct.n_out + k] = __builtin_nan("");
     }
-    while (r < r_end) {
+    while (r < r_stop) {
         if (steps >= ct.max_steps) {
             status = RT_SHELL_STEP_LIMIT;
             break;
@@ -161,9 +162,10 @@ __global__ void shell_ode_kernel(const ShellModel m, const ShellRegions rg, cons
             status = RT_SHELL_ESCAPED;  // beyond r_escape the reference sets dv/dr = -inf and its solver stops
             break;
         }
-        const double target = ct.n_out > 0 && next_out < ct.n_out
-                                  ? r0 + (double)(next_out + 1) / (double)ct.n_out * (r_end - r0)
-                                  : r_end;
+        const double next_sample =
+            ct.n_out > 0 && next_out < ct.n_out ? r0 + (double)(next_out + 1) / (double)ct.n_out * (r_end - r0) : r_end;
+        const bool to_sample = next_sample <= r_stop;
+        const double target = to_sample ? next_sample : r_stop;
         bool lands = false;
         double hs = fmin(h, ct.max_step);
         if (r + hs >= target || target - (r + hs) < 1e-12 * target) {
@@ -216,7 +218,7 @@ __global__ void shell_ode_kernel(const ShellModel m, const ShellRegions rg, cons
                 r_vmax = r;
                 t_vmax = t;
             }
-            if (lands && ct.n_out > 0 && next_out < ct.n_out) {
+            if (lands && to_sample && ct.n_out > 0 && next_out < ct.n_out) {
                 out.v_out[(size_t)i * ct.n_out + next_out] = v;
                 out.t_out[(size_t)i * ct.n_out + next_out] = t;
                 ++next_out;
@@ -233,6 +235,7 @@ __global__ void shell_ode_kernel(const ShellModel m, const ShellRegions rg, cons
             }
         }
     }
+    if (status == RT_SHELL_REACHED_END && r_stop < r_end) status = RT_SHELL_ESCAPED;
     out.v_max[i] = v_max;
     out.r_vmax[i] = r_vmax;
     out.t_vmax[i] = t_vmax;
