@@ -102,6 +102,10 @@ def test_known_answers_of_the_reference_run(engine):
     np.testing.assert_allclose(sol.v_max[moving] / 1e5, want_v[moving], rtol=1e-2)
     np.testing.assert_allclose(sol.r_last[moving] / CM_PC, want_r[moving], rtol=1e-2)
     assert np.all(sol.status[moving] == shell.abi.SHELL_STALLED)
+    # the made-up strongly super-Eddington regions run into the escape radius (MC code.py:951-953)
+    esc = sol.status == shell.abi.SHELL_ESCAPED
+    assert esc.any() and not esc[real].any()
+    np.testing.assert_allclose(sol.r_last[esc], 10000 * CM_PC, rtol=1e-12)
     # sub-Eddington regions never get going: the table holds 0 for them
     still = real & (want_v == 0)
     assert np.all(sol.status[still] == shell.abi.SHELL_STALLED)
