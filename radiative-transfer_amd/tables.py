@@ -343,6 +343,43 @@ def photon_pdf(wl_um, sed):
     return np.gradient(cdf), cdf
 
 
+def csfr_time_steps(n_ages):
+    """Width in years of each BPASS age bin as the reference writes it (MC code.py:1233-1239): the first bin
+    reaches from 0 to 10^6.05 yr, bin i >= 1 from 10^(6.05 + 0.1 (i-1)) to 10^(6.15 + 0.1 (i-1))."""
+    # Python-scalar powers, as the reference's loop: NumPy's vectorised pow differs in the last bit
+    return np.array([10 ** 6.05 if i == 0 else 10 ** (6.15 + 0.1 * (i - 1)) - 10 ** (6.05 + 0.1 * (i - 1))
+                     for i in range(n_ages)])
+
+
+def continuous_star_formation_sed(spectra, age, rate=1.0):
+    """ContinuousStarFormationSED (MC code.py:1075-1088): spectrum of a population that has formed stars at
+    `rate` solar masses per year for `age` years, as the sum over the instantaneous-burst columns (10^6 solar
+    masses each) with log age <= log10(age), each times its bin width, added in order of age.
+    spectra: mapping {log age: L_lambda}."""
+    ages = sorted(spectra, key=float)
+    dt = csfr_time_steps(len(ages))
+    ages_exp = np.power(10, np.array(ages, dtype=float))    # vectorised, as MC code.py:1220 (pow's last bit matters)
+    sed = np.zeros_like(np.asarray(spectra[ages[0]], dtype=float))
+    for j, a in enumerate(ages):
+        if ages_exp[j] > age:
+            break
+        sed = sed + np.asarray(spectra[a], dtype=float) * dt[j] * rate
+    return sed / 10 ** 6
+
+
+def continuous_sfr_spectra(spectra, rate=1.0):
+    """Every column of the reference's `continuous_SFR` frame (MC code.py:1245-1255): column k is
+    continuous_star_formation_sed(spectra, 10^age_k, rate).  One running sum over the ages instead of the
+    reference's 51 separate sums; the additions happen in the same order, so the columns are bit-identical.
+    Returns ({log age: L_lambda}, mass formed up to each age as at MC code.py:1257-1259)."""
+    ages = sorted(spectra, key=float)
+    dt = csfr_time_steps(len(ages))
+    run = np.cumsum(np.stack([np.asarray(spectra[a], dtype=float) * dt[j] * rate for j, a in enumerate(ages)]), axis=0)
+    mass = dt.copy()
+    mass[1:] *= rate
+    return {a: run[k] / 10 ** 6 for k, a in enumerate(ages)}, np.cumsum(mass)
+
+
 def join_on_wavelength(range_wl, grain):
     """What CreatePhotons' left-join does for every candidate wavelength (MC code.py:394,403-408):
     round to 4 decimals, exact match on Grain_data.WL.  Returns (g, Albedo, Scale) aligned with

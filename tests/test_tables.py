@@ -130,3 +130,24 @@ def test_l_edd_dataframe_matches_per_age_get_kappas():
             assert df[f"kappa_av_F_{sp}"][i] == pytest.approx(k["kappa_av_F"], rel=1e-12)
             assert df["L_bol_BPASS"][i] == pytest.approx(k["L"], rel=1e-14)
         assert np.allclose(df[f"L_Edd_{sp}"], 1.299e4 / (df[f"kappa_av_RP_{sp}"] * 0.01), rtol=1e-15)
+
+
+def test_continuous_star_formation_matches_reference():
+    """ContinuousStarFormationSED (MC code.py:1075-1088) on a seeded synthetic spectra table, every 997th
+    wavelength of the reference's output stored in tests/golden/csfr.npz (oracle/make_golden_csfr.py)."""
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "csfr.npz"))
+    rng = np.random.default_rng(20260111)
+    base = rng.random((51, 100000)) * np.logspace(3, -2, 51)[:, None]
+    spectra = {f"{6.0 + 0.1 * j:.1f}": base[j] for j in range(51)}
+    stride = int(z["stride"])
+    assert np.array_equal(tables.csfr_time_steps(51), z["delta_t"])
+    for rate in (1, 3.5):
+        cols, mass = tables.continuous_sfr_spectra(spectra, rate)
+        got = np.stack([cols[a][::stride] for a in sorted(cols, key=float)])
+        assert np.array_equal(got, z[f"csfr_rate_{rate}"])          # same additions in the same order
+        assert mass[0] == 10 ** 6.05 and np.all(np.diff(mass) > 0)
+        on_grid = np.power(10, np.array(sorted(cols, key=float), dtype=float))
+        for k in (0, 13, 50):
+            assert np.array_equal(tables.continuous_star_formation_sed(spectra, on_grid[k], rate)[::stride], got[k])
+    for age, want in zip(z["off_grid_ages"], z["off_grid"]):
+        assert np.array_equal(tables.continuous_star_formation_sed(spectra, float(age))[::stride], want)
