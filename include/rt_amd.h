@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 2
+#define RT_ABI_VERSION 3
 
 typedef enum rt_status {
     RT_OK = 0,
@@ -40,7 +40,37 @@ typedef enum rt_status {
 /* boundary condition of the lower face, MC code.py:522-574 */
 enum { RT_BOUNDARY_REFLECT = 0, RT_BOUNDARY_ABSORB = 1, RT_BOUNDARY_REEMIT = 2 };
 /* scattering law, MC code.py:732-760 and Numpy_random_walk.py:369-396 */
-enum { RT_SCATTER_HG = 0, RT_SCATTER_ISO = 1, RT_SCATTER_DRAINE = 2 };
+enum { RT_SCATTER_HG = 0, RT_SCATTER_ISO = 1, RT_SCATTER_DRAINE = 2, RT_SCATTER_DRAINE_EXACT = 3 };
+/* RT_SCATTER_DRAINE restates the reference's rejection sampler (Numpy_random_walk.py:106-130) photon by photon,
+ * including its defect: candidates are accepted where pdf(mu) > y with y uniform on [0,1), so the density is
+ * clipped wherever pdf > 1 and the sampler is slow where pdf << 1.  Gray loop order only, as in the reference.
+ * RT_SCATTER_DRAINE_EXACT (no counterpart in the reference, which marks its sampler "not currently functioning",
+ * MC code.py:1006) draws from the same phase function
+ *     p(mu) ~ (1 + alpha mu^2) / (1 + g^2 - 2 g mu)^(3/2),      0 <= alpha <= 1,
+ * exactly: a Henyey-Greenstein candidate by the reference's own inverse CDF (MC code.py:439), accepted with
+ * probability (1 + alpha mu^2) / (1 + alpha); one uniform pair (y, xi) of the photon's stream per try, at most
+ * 1 + alpha tries on average.  Any loop order; g per photon (per wavelength) as for RT_SCATTER_HG.
+ * alpha = 0 accepts every candidate and gives Henyey-Greenstein; g = 0, alpha = 1 is Rayleigh scattering. */
+/* geometry of the dust layer.
+ *   RT_GEOM_SLAB   the reference's plane-parallel slab: z is the optical depth above the emitting face and mu
+ *                  the cosine to the slab normal (TakeStep, MC code.py:493-508).
+ *   RT_GEOM_SHELL  (no counterpart in the reference) a spherical shell of uniform density between the radii
+ *                  r_in and r_in + thickness around the source: z = r - r_in in optical-depth units of the
+ *                  photon's wavelength, 0 <= z <= tau*Scale, and mu the cosine to the local radial direction.
+ *                  r_in = shell_inner * tau*Scale (shell_inner = inner radius / thickness > 0).  A flight of
+ *                  optical length s moves the photon along a straight line:
+ *                      r' = sqrt(r^2 + s^2 + 2 r s mu),   mu' = (r mu + s) / r'.
+ *                  The cavity r < r_in is empty: a photon that reaches it crosses it and re-enters the shell
+ *                  on the far side (RT_BOUNDARY_REFLECT, counted in RT_CNT_BOUNDARY_HITS, no momentum
+ *                  exchanged), is removed there (RT_BOUNDARY_ABSORB) or is replaced by a new photon
+ *                  (RT_BOUNDARY_REEMIT).  One escape test per flight, r' > r_in + thickness, in either loop
+ *                  order; every escaping photon is tallied (RT_SUM_ESCAPED = radial momentum at the outer
+ *                  face) and enters mu_hist.  Momentum is not conserved along a straight line in radial
+ *                  coordinates, so the deposited radial momentum is RT_SUM_DUST_MOMENTUM (summed at the
+ *                  collisions) and t_i in RT_SUM_TRANSFER_* is photon i's share of it.  depth bins are radial
+ *                  bins.  shell_inner -> infinity recovers the slab with a reflecting lower face.
+ *                  Walk only (rt_run / rt_run_device), not rt_replay. */
+enum { RT_GEOM_SLAB = 0, RT_GEOM_SHELL = 1 };
 /* order of the tests inside one loop iteration:
  *   RT_ORDER_MC    step, escape(tallied), boundary, escape(logged), absorb, scatter  (MC code.py:657-767)
  *   RT_ORDER_GRAY  step, boundary, escape(tallied+logged), absorb, scatter           (Numpy_random_walk.py:313-396)
@@ -97,7 +127,8 @@ enum {
  *   u = (w + 1/2) / 2^32: block k gives (azimuth, cosine) of the scattering BEFORE flight k in words 0-1 and
  *   (step, absorb) of flight k in words 2-3; block 0's words 0-1 (no scattering precedes the first flight)
  *   are the 52-bit emission draw.  Steps are then quantised to 2^-32 in xi (longest step 22.9), angles to
- *   2^-32 of a turn.  Not available with RT_SCATTER_DRAINE. */
+ *   2^-32 of a turn.  Not available with RT_SCATTER_DRAINE / RT_SCATTER_DRAINE_EXACT (their rejection loops need
+ *   more than one block per iteration). */
 enum rt_rng_mode { RT_RNG_PHILOX52 = 0, RT_RNG_PHILOX32X4 = 1 };
 
 typedef struct rt_params {
@@ -121,8 +152,9 @@ typedef struct rt_params {
     const double* tau_atm;         /* [n_atm] reference optical depth of each atmosphere (tau_list_calc) */
     const uint64_t* n_photons;     /* [n_atm] photons per atmosphere (photon_reduction already applied) */
     int32_t rng_mode;              /* RT_RNG_* */
-    int32_t reserved_;             /* 0 */
+    int32_t geometry;              /* RT_GEOM_* */
     const int32_t* table_of_atm;   /* [n_atm] which table of rt_set_tables_multi an atmosphere uses; NULL = table 0 */
+    double shell_inner;            /* RT_GEOM_SHELL: inner radius in units of the shell's thickness (> 0) */
 } rt_params;
 
 /* Host-side result arrays of one sweep; any pointer may be NULL to skip it. */

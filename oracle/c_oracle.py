@@ -38,13 +38,15 @@ def _dp(a):
 
 def make_params(tau, n_photons, *, boundary="reflect", scatter="hg", order="mc", rand_mu=0, abs_only=0,
                 n_mu_bins=10, n_depth_bins=0, max_events=0, n_slabs=8, rank=0, world=1, seed=0x5EED2026,
-                photon_id_base=0, monochromatic=0.0, alpha=0.3, h=6.6261e-27, rng="philox52", table_of_atm=None):
+                photon_id_base=0, monochromatic=0.0, alpha=0.3, h=6.6261e-27, rng="philox52", table_of_atm=None,
+                geometry="slab", shell_inner=0.0):
     tau = np.ascontiguousarray(np.atleast_1d(tau), dtype=np.float64)
     npn = np.ascontiguousarray(np.broadcast_to(np.atleast_1d(n_photons), tau.shape), dtype=np.uint64)
     p = abi.RtParams(len(tau), abi.BOUNDARY[boundary], abi.SCATTER[scatter], abi.ORDER[order], int(rand_mu),
                      int(abs_only), int(n_mu_bins), int(n_depth_bins), int(max_events), int(n_slabs), int(rank),
                      int(world), int(seed), int(photon_id_base), float(monochromatic), float(alpha), float(h),
-                     _dp(tau), npn.ctypes.data_as(abi.c_u64_p), abi.RNG[rng], 0, None)
+                     _dp(tau), npn.ctypes.data_as(abi.c_u64_p), abi.RNG[rng], abi.GEOMETRY[geometry],
+                     None, float(shell_inner))
     p._keep = (tau, npn)
     if table_of_atm is not None:
         tab = np.ascontiguousarray(np.broadcast_to(np.atleast_1d(table_of_atm), tau.shape), dtype=np.int32)

@@ -228,12 +228,14 @@ static double draine_pdf(double g, double alpha, double m) {
 static void walk_one(const rt_params* p, double tau, const tables_t* t, stream_t* s, consts_t c, acc_t* a,
                      uint64_t* mu_hist, double* depth_mom, double* depth_en, rt_photon_trace* tr) {
     const int gray = p->loop_order == RT_ORDER_GRAY;
+    const int shell = p->geometry == RT_GEOM_SHELL;
     const double h = p->h;
     const int max_ev = p->max_events_per_photon > 0 ? p->max_events_per_photon : (1 << 20);
     double w = gray ? c.lam : 1 / c.lam;
     double zmax = tau * c.scale;
     double z = 0.0, mu = c.mu0;
     double p0 = mu * w * h, e1 = 0.0, b = 0.0;
+    double dep = 0.0; /* RT_GEOM_SHELL: radial momentum deposited by this photon */
     int fate = 0, n_scatter = 0, iter = 0;
     a->counts[RT_CNT_PHOTONS]++;
     a->sums[RT_SUM_INITIAL] += p0;
@@ -242,13 +244,55 @@ static void walk_one(const rt_params* p, double tau, const tables_t* t, stream_t
         if (iter >= max_ev || !draw(s, &u)) { fate = RT_FATE_GUARD; break; }
         iter++;
         a->counts[RT_CNT_FLIGHTS]++;
-        z += -log(u) * mu;
-        if (!gray && z > zmax) {
+        if (shell) {
+            /* straight flight of optical length `path` in a uniform spherical shell (RT_GEOM_SHELL in rt_amd.h) */
+            double path = -log(u);
+            double rin = p->shell_inner * zmax, r = rin + z;
+            int reemitted = 0;
+            if (mu < 0) {
+                double d2 = rin * rin - r * r * (1 - mu * mu);
+                if (d2 > 0) {
+                    double half = sqrt(d2), d_in = -r * mu - half;
+                    if (d_in < 0) d_in = 0;
+                    if (path >= d_in) {
+                        double mu_c = half / rin;
+                        a->counts[RT_CNT_BOUNDARY_HITS]++;
+                        if (p->boundary == RT_BOUNDARY_REFLECT) {
+                            path -= d_in; r = rin; z = 0; mu = mu_c;
+                        } else if (p->boundary == RT_BOUNDARY_ABSORB) {
+                            b += -mu_c * w * h;
+                            fate = RT_FATE_BOUNDARY;
+                            break;
+                        } else {
+                            b += -mu_c * w * h;
+                            a->counts[RT_CNT_REEMITTED]++;
+                            if (s->use_philox) emit_philox(p, t, s, &c);
+                            w = gray ? c.lam : 1 / c.lam;
+                            zmax = tau * c.scale;
+                            z = 0.0;
+                            mu = c.mu0;
+                            a->sums[RT_SUM_REEMITTED] += mu * w * h;
+                            reemitted = 1;
+                        }
+                    }
+                }
+            }
+            if (!reemitted) {
+                double q = path * (path + 2 * r * mu), r2 = sqrt(r * r + q);
+                double m2 = (r * mu + path) / r2;
+                mu = m2 > 1 ? 1 : (m2 < -1 ? -1 : m2);
+                z = z + q / (r2 + r);
+                if (z < 0) z = 0;
+            }
+        } else {
+            z += -log(u) * mu;
+        }
+        if (!shell && !gray && z > zmax) {
             fate = RT_FATE_ESCAPED;
             e1 = mu * w * h;
             break;
         }
-        if (z <= 0) {
+        if (!shell && z <= 0) {
             double pb = mu * w * h;
             a->counts[RT_CNT_BOUNDARY_HITS]++;
             if (p->boundary == RT_BOUNDARY_REFLECT) {
@@ -271,7 +315,7 @@ static void walk_one(const rt_params* p, double tau, const tables_t* t, stream_t
             }
         }
         if (z > zmax) {
-            if (gray) {
+            if (gray || shell) {
                 fate = RT_FATE_ESCAPED;
                 e1 = mu * w * h;
             } else {
@@ -286,6 +330,7 @@ static void walk_one(const rt_params* p, double tau, const tables_t* t, stream_t
             double pa = mu * w * h;
             a->sums[RT_SUM_DUST_MOMENTUM] += pa;
             a->sums[RT_SUM_ABSORBED_ENERGY] += w * h;
+            dep += pa;
             if (p->n_depth_bins > 0) {
                 int k = (int)floor(p->n_depth_bins * (z / zmax));
                 if (k < 0) k = 0;
@@ -302,14 +347,22 @@ static void walk_one(const rt_params* p, double tau, const tables_t* t, stream_t
         if (gray && p->scatter == RT_SCATTER_HG && c.g == 0) iso = 1;
         double u_phi, u_s, mu_prime = 0;
         if (!draw(s, &u_phi)) { fate = RT_FATE_GUARD; break; }
-        if (p->scatter == RT_SCATTER_DRAINE && !iso) {
+        if ((p->scatter == RT_SCATTER_DRAINE || p->scatter == RT_SCATTER_DRAINE_EXACT) && !iso) {
             /* draws are consumed in aligned pairs: the partner of the azimuth draw is skipped */
             int ok = draw(s, &u_s);
             while (ok) {
                 double y, cnd;
                 if (!draw(s, &y) || !draw(s, &cnd)) { ok = 0; break; }
                 cnd = 2 * cnd - 1;
-                if (draine_pdf(c.g, p->alpha, cnd) > y) { mu_prime = cnd; break; }
+                if (p->scatter == RT_SCATTER_DRAINE) {
+                    if (draine_pdf(c.g, p->alpha, cnd) > y) { mu_prime = cnd; break; }
+                } else { /* Henyey-Greenstein candidate, kept with probability (1 + alpha mu^2) / (1 + alpha) */
+                    if (c.g != 0) {
+                        double g = c.g, q = (1 - g * g) / (1 + g * cnd);
+                        cnd = 1 / (2 * g) * (1 + g * g - q * q);
+                    }
+                    if (1 + p->alpha * cnd * cnd > y * (1 + p->alpha)) { mu_prime = cnd; break; }
+                }
             }
             if (!ok) { fate = RT_FATE_GUARD; break; }
         } else {
@@ -334,6 +387,7 @@ static void walk_one(const rt_params* p, double tau, const tables_t* t, stream_t
         {
             double dp = (mu_old - mu) * w * h;
             a->sums[RT_SUM_DUST_MOMENTUM] += dp;
+            dep += dp;
             if (p->n_depth_bins > 0) {
                 int k = (int)floor(p->n_depth_bins * (z / zmax));
                 if (k < 0) k = 0;
@@ -349,7 +403,7 @@ static void walk_one(const rt_params* p, double tau, const tables_t* t, stream_t
         case RT_FATE_BOUNDARY: a->counts[RT_CNT_BOUNDARY_ABSORBED]++; break;
         default: a->counts[RT_CNT_GUARD]++; break;
     }
-    if (mu_hist && ((fate == RT_FATE_ESCAPED && gray) || fate == RT_FATE_ESCAPED_UNCOUNTED)) {
+    if (mu_hist && ((fate == RT_FATE_ESCAPED && (gray || shell)) || fate == RT_FATE_ESCAPED_UNCOUNTED)) {
         int k = (int)floor(p->n_mu_bins * mu);
         if (k < 0) k = 0;
         if (k > p->n_mu_bins) k = p->n_mu_bins;
@@ -357,7 +411,7 @@ static void walk_one(const rt_params* p, double tau, const tables_t* t, stream_t
     }
     a->sums[RT_SUM_BOUNDARY] += b;
     {
-        double ti = p0 - e1 + b;
+        double ti = shell ? dep : p0 - e1 + b;
         a->sums[RT_SUM_TRANSFER_SQ] += ti * ti;
         a->sums[RT_SUM_TRANSFER_P0] += ti * p0;
         a->sums[RT_SUM_P0_SQ] += p0 * p0;

@@ -11,10 +11,11 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "csrc", "librt_amd.so")
 
-RT_ABI_VERSION = 2
+RT_ABI_VERSION = 3
 
 BOUNDARY = {"reflect": 0, "absorb": 1, "reemit": 2}
-SCATTER = {"hg": 0, "iso": 1, "draine": 2}
+SCATTER = {"hg": 0, "iso": 1, "draine": 2, "draine_exact": 3}
+GEOMETRY = {"slab": 0, "shell": 1}
 ORDER = {"mc": 0, "gray": 1}
 RNG = {"philox52": 0, "philox32x4": 1}
 
@@ -39,7 +40,8 @@ class RtParams(C.Structure):
         ("seed", C.c_uint64), ("photon_id_base", C.c_uint64),
         ("monochromatic_wl", C.c_double), ("alpha", C.c_double), ("h", C.c_double),
         ("tau_atm", c_double_p), ("n_photons", c_u64_p),
-        ("rng_mode", C.c_int32), ("reserved_", C.c_int32), ("table_of_atm", C.POINTER(C.c_int32)),
+        ("rng_mode", C.c_int32), ("geometry", C.c_int32), ("table_of_atm", C.POINTER(C.c_int32)),
+        ("shell_inner", C.c_double),
     ]
 
 

@@ -102,7 +102,8 @@ int check_common(const rt_params* p) {
     if (!p->tau_atm || !p->n_photons) return fail(RT_ERR_INVALID, "tau_atm / n_photons is NULL");
     if (p->boundary < 0 || p->boundary > 2)
         return fail(RT_ERR_INVALID, "No valid boundary condition specified (boundary=%d)", p->boundary);
-    if (p->scatter < 0 || p->scatter > 2) return fail(RT_ERR_INVALID, "scatter=%d is not hg/iso/draine", p->scatter);
+    if (p->scatter < 0 || p->scatter > 3)
+        return fail(RT_ERR_INVALID, "scatter=%d is not hg/iso/draine/draine_exact", p->scatter);
     if (p->loop_order < 0 || p->loop_order > 1) return fail(RT_ERR_INVALID, "loop_order=%d", p->loop_order);
     if (p->n_mu_bins < 0 || p->n_mu_bins > 4096) return fail(RT_ERR_LIMIT, "n_mu_bins must be in [0, 4096]");
     if (p->n_depth_bins < 0 || p->n_depth_bins > 1024) return fail(RT_ERR_LIMIT, "n_depth_bins must be in [0, 1024]");
@@ -112,8 +113,14 @@ int check_common(const rt_params* p) {
                     "wavelength-dependent reference script)");
     if (p->rng_mode != RT_RNG_PHILOX52 && p->rng_mode != RT_RNG_PHILOX32X4)
         return fail(RT_ERR_INVALID, "rng_mode=%d is not RT_RNG_PHILOX52 / RT_RNG_PHILOX32X4", p->rng_mode);
-    if (p->rng_mode == RT_RNG_PHILOX32X4 && p->scatter == RT_SCATTER_DRAINE)
+    if (p->rng_mode == RT_RNG_PHILOX32X4 && (p->scatter == RT_SCATTER_DRAINE || p->scatter == RT_SCATTER_DRAINE_EXACT))
         return fail(RT_ERR_INVALID, "RT_RNG_PHILOX32X4 has one block per loop iteration; the Draine rejection loop needs more");
+    if (p->scatter == RT_SCATTER_DRAINE_EXACT && !(p->alpha >= 0.0 && p->alpha <= 1.0))
+        return fail(RT_ERR_INVALID, "scatter='draine_exact' needs 0 <= alpha <= 1 (got %g)", p->alpha);
+    if (p->geometry != RT_GEOM_SLAB && p->geometry != RT_GEOM_SHELL)
+        return fail(RT_ERR_INVALID, "geometry=%d is not RT_GEOM_SLAB / RT_GEOM_SHELL", p->geometry);
+    if (p->geometry == RT_GEOM_SHELL && !(p->shell_inner > 0.0 && p->shell_inner < 1e300))
+        return fail(RT_ERR_INVALID, "RT_GEOM_SHELL needs a finite shell_inner > 0 (got %g)", p->shell_inner);
     return RT_OK;
 }
 
@@ -130,6 +137,8 @@ rt::Cfg make_cfg(const rt_ctx* ctx, const rt_params* p) {
     c.max_events = p->max_events_per_photon > 0 ? p->max_events_per_photon : (1 << 20);
     c.alpha = p->alpha;
     c.h = p->h;
+    c.geometry = p->geometry;
+    c.shell_inner = p->shell_inner;
     c.k0 = (uint32_t)p->seed;
     c.k1 = (uint32_t)(p->seed >> 32);
     c.id_base = p->photon_id_base;
@@ -443,7 +452,8 @@ int rt_run_device(rt_ctx* ctx, const rt_params* p, void* d_slab_sums, void* d_co
         RT_HIP(hipMemsetAsync(d_depth, 0, sizeof(double) * 2 * (size_t)p->n_atm * p->n_depth_bins, stream));
 
     const bool fast = p->loop_order == RT_ORDER_MC && p->boundary == RT_BOUNDARY_REFLECT &&
-                      p->scatter == RT_SCATTER_HG && p->n_depth_bins == 0 && !p->abs_only;
+                      p->scatter == RT_SCATTER_HG && p->n_depth_bins == 0 && !p->abs_only &&
+                      p->geometry == RT_GEOM_SLAB;
     const size_t lds = rt::walk_lds_bytes(cfg, fast);
     if (lds > 64 * 1024) return fail(RT_ERR_LIMIT, "histogram bins need %zu bytes of LDS per block (max 65536)", lds);
     const bool packed = p->rng_mode == RT_RNG_PHILOX32X4;
@@ -521,6 +531,7 @@ int rt_replay(rt_ctx* ctx, const rt_params* p, int64_t n, int32_t max_draws, con
     int rc = check_common(p);
     if (rc) return rc;
     if (n < 0 || max_draws < 0) return fail(RT_ERR_INVALID, "negative size");
+    if (p->geometry != RT_GEOM_SLAB) return fail(RT_ERR_INVALID, "rt_replay walks the slab geometry only");
     if (n > 0 && (!xi || !lambda || !g || !albedo || !scale || !mu0)) return fail(RT_ERR_INVALID, "NULL input array");
     if (!out) return fail(RT_ERR_INVALID, "out is NULL");
     if ((double)n * (double)max_draws > 4e9) return fail(RT_ERR_LIMIT, "xi matrix larger than 4e9 entries");

@@ -97,6 +97,8 @@ struct Cfg {
     int32_t boundary, scatter, order, rand_mu, abs_only;
     int32_t n_mu_bins, n_depth_bins, max_events;
     double alpha, h;
+    int32_t geometry, pad_;
+    double shell_inner;  // RT_GEOM_SHELL: inner radius / thickness
     uint32_t k0, k1;
     uint64_t id_base;
     // emission tables
@@ -109,6 +111,7 @@ struct Cfg {
 
 struct Photon {
     double z, mu, wh, g, albedo, zmax, inv2g, opg2, omg2, p0, e1, b;
+    double dep;  // RT_GEOM_SHELL: radial momentum this photon has deposited so far
     uint32_t iter;
     int32_t n_scatter;
 };
@@ -271,6 +274,52 @@ __device__ __forceinline__ double draine_pdf(double g, double alpha, double m) {
            (1.0 + alpha * m * m) / (d * sqrt(d));
 }
 
+// A straight flight of optical length `path` through a uniform spherical shell (RT_GEOM_SHELL): ph.z is the
+// height above the inner radius r_in = shell_inner * zmax, ph.mu the cosine to the local radial direction.
+// A photon that reaches the empty cavity crosses it and re-enters on the far side with the mirrored cosine
+// (reflect), or ends / is replaced there.  Returns a fate or 0.  No counterpart in the reference.
+template <class Reemit, class AccT>
+__device__ __forceinline__ int fly_shell(const Cfg& cfg, Photon& ph, double path, int boundary, AccT& acc,
+                                         Reemit&& reemit) {
+    const double rin = cfg.shell_inner * ph.zmax;
+    double r = rin + ph.z;
+    if (ph.mu < 0.0) {
+        const double d2 = rin * rin - r * r * (1.0 - ph.mu * ph.mu);  // r_in^2 - (impact parameter)^2
+        if (d2 > 0.0) {
+            const double half = sqrt(d2);  // half the chord through the cavity
+            double d_in = -r * ph.mu - half;
+            d_in = d_in > 0.0 ? d_in : 0.0;
+            if (path >= d_in) {
+                acc.count(RT_CNT_BOUNDARY_HITS);
+                const double mu_c = half / rin;  // cosine to the radial direction on leaving the cavity
+                if (boundary == RT_BOUNDARY_REFLECT) {
+                    path -= d_in;
+                    r = rin;
+                    ph.z = 0.0;
+                    ph.mu = mu_c;
+                } else if (boundary == RT_BOUNDARY_ABSORB) {
+                    ph.b += -mu_c * ph.wh;
+                    return RT_FATE_BOUNDARY;
+                } else {
+                    ph.b += -mu_c * ph.wh;
+                    acc.count(RT_CNT_REEMITTED);
+                    reemit(ph);
+                    acc.add(RT_SUM_REEMITTED, ph.mu * ph.wh);
+                    return 0;  // the new photon interacts at z = 0, as in the slab (MC code.py:539-547, :700)
+                }
+            }
+        }
+    }
+    const double q = path * (path + 2.0 * r * ph.mu);  // r'^2 - r^2
+    const double r2 = sqrt(r * r + q);
+    double mu = (r * ph.mu + path) / r2;
+    mu = mu > 1.0 ? 1.0 : (mu < -1.0 ? -1.0 : mu);
+    double z = ph.z + q / (r2 + r);  // r' - r without cancellation
+    ph.z = z > 0.0 ? z : 0.0;        // a grazing pass of the cavity can round to -1 ulp
+    ph.mu = mu;
+    return 0;
+}
+
 // ---------------------------------------------------------------------------
 // One loop iteration of one photon, in two halves.
 //   fly()      TakeStep, escape / boundary / escape tests, Absorb.  Returns the photon's
@@ -286,6 +335,7 @@ __device__ __forceinline__ int fly(const Cfg& cfg, Photon& ph, double u_step, do
     const bool gray = FAST ? false : cfg.order == RT_ORDER_GRAY;
     const int boundary = FAST ? (int)RT_BOUNDARY_REFLECT : cfg.boundary;
     const bool depth = FAST ? false : cfg.n_depth_bins > 0;
+    const bool shell = FAST ? false : cfg.geometry == RT_GEOM_SHELL;
 
     if (bounded && avail < 1) return RT_FATE_GUARD;
     ph.iter++;
@@ -293,13 +343,19 @@ __device__ __forceinline__ int fly(const Cfg& cfg, Photon& ph, double u_step, do
     n_used += 1;
 
     // TakeStep
-    ph.z += -log_unit(u_step, hist.log_table) * ph.mu;
+    const double path = -log_unit(u_step, hist.log_table);
+    if (shell) {
+        const int f = fly_shell(cfg, ph, path, boundary, acc, reemit);
+        if (f != 0) return f;
+    } else {
+        ph.z += path * ph.mu;
+    }
 
-    if (!gray && ph.z > ph.zmax) {  // first escape test: momentum tallied
+    if (!shell && !gray && ph.z > ph.zmax) {  // first escape test: momentum tallied
         ph.e1 = ph.mu * ph.wh;
         return RT_FATE_ESCAPED;
     }
-    if (ph.z <= 0.0) {  // CheckBoundary
+    if (!shell && ph.z <= 0.0) {  // CheckBoundary
         const double pb = ph.mu * ph.wh;
         acc.count(RT_CNT_BOUNDARY_HITS);
         if (boundary == RT_BOUNDARY_REFLECT) {
@@ -316,8 +372,8 @@ __device__ __forceinline__ int fly(const Cfg& cfg, Photon& ph, double u_step, do
             acc.add(RT_SUM_REEMITTED, ph.mu * ph.wh);
         }
     }
-    if (ph.z > ph.zmax) {  // second escape test (the only one in gray order)
-        if (gray) {
+    if (ph.z > ph.zmax) {  // second escape test (the only one in gray order and in a shell)
+        if (gray || shell) {
             ph.e1 = ph.mu * ph.wh;
             return RT_FATE_ESCAPED;
         }
@@ -333,6 +389,7 @@ __device__ __forceinline__ int fly(const Cfg& cfg, Photon& ph, double u_step, do
         const double pa = ph.mu * ph.wh;
         acc.add(RT_SUM_DUST_MOMENTUM, pa);
         acc.add(RT_SUM_ABSORBED_ENERGY, ph.wh);
+        if (shell) ph.dep += pa;
         if (depth) {
             const int k = depth_bin(cfg, ph);
             atomicAdd(&hist.depth_mom[k], pa);
@@ -349,6 +406,7 @@ __device__ __forceinline__ int scatter(const Cfg& cfg, Photon& ph, Src& src, dou
     const bool gray = FAST ? false : cfg.order == RT_ORDER_GRAY;
     const int law = FAST ? (int)RT_SCATTER_HG : cfg.scatter;
     const bool depth = FAST ? false : cfg.n_depth_bins > 0;
+    const bool shell = FAST ? false : cfg.geometry == RT_GEOM_SHELL;
     if (Src::kBounded && avail2 < 2) return RT_FATE_GUARD;
     src.used(2);
     const double mu_old = ph.mu;
@@ -359,7 +417,7 @@ __device__ __forceinline__ int scatter(const Cfg& cfg, Photon& ph, Src& src, dou
     }
     double mu_prime;
     bool direct = false;
-    if (!FAST && law == RT_SCATTER_DRAINE && !iso) {
+    if (!FAST && (law == RT_SCATTER_DRAINE || law == RT_SCATTER_DRAINE_EXACT) && !iso) {
         mu_prime = 0.0;
         bool ok = false;
         for (;;) {  // rejection sampling of the Draine phase function, one pair (y, candidate) per try
@@ -368,7 +426,17 @@ __device__ __forceinline__ int scatter(const Cfg& cfg, Photon& ph, Src& src, dou
             if (Src::kBounded && av < 2) break;
             src.used(2);
             cand = 2.0 * cand - 1.0;
-            if (draine_pdf(ph.g, cfg.alpha, cand) > y) {
+            bool accept;
+            if (law == RT_SCATTER_DRAINE) {
+                accept = draine_pdf(ph.g, cfg.alpha, cand) > y;  // uniform candidate, the reference's test
+            } else {
+                if (ph.g != 0.0) {  // Henyey-Greenstein candidate (MC code.py:439); g = 0 is its isotropic limit
+                    const double q = ph.omg2 / (1.0 + ph.g * cand);
+                    cand = ph.inv2g * (ph.opg2 - q * q);
+                }
+                accept = 1.0 + cfg.alpha * cand * cand > y * (1.0 + cfg.alpha);
+            }
+            if (accept) {
                 mu_prime = cand;
                 ok = true;
                 break;
@@ -403,6 +471,7 @@ __device__ __forceinline__ int scatter(const Cfg& cfg, Photon& ph, Src& src, dou
     acc.count(RT_CNT_SCATTER);
     const double dp = (mu_old - mu_new) * ph.wh;
     acc.add(RT_SUM_DUST_MOMENTUM, dp);
+    if (shell) ph.dep += dp;
     if (depth) atomicAdd(&hist.depth_mom[depth_bin(cfg, ph)], dp);
     return 0;
 }
@@ -425,8 +494,9 @@ __device__ __forceinline__ int flight(const Cfg& cfg, Photon& ph, Src& src, Acc&
 
 // Bookkeeping when a photon's history ends.
 template <class AccT>
-__device__ __forceinline__ void retire(const Cfg& cfg, const Photon& ph, int fate, AccT& acc, const Hist& hist) {
-    const bool gray = cfg.order == RT_ORDER_GRAY;
+__device__ __forceinline__ void retire(const Cfg& cfg, const Photon& ph, int fate, AccT& acc, const Hist& hist,
+                                       bool shell = false) {
+    const bool gray = cfg.order == RT_ORDER_GRAY || shell;  // a shell has one escape test: every escape is logged
     acc.count_if(RT_CNT_ESCAPED, fate == RT_FATE_ESCAPED);
     acc.count_if(RT_CNT_ESCAPED_UNCOUNTED, fate == RT_FATE_ESCAPED_UNCOUNTED);
     acc.count_if(RT_CNT_ABSORBED, fate == RT_FATE_ABSORBED);
@@ -434,7 +504,7 @@ __device__ __forceinline__ void retire(const Cfg& cfg, const Photon& ph, int fat
     acc.count_if(RT_CNT_GUARD, fate == RT_FATE_GUARD);
     acc.add(RT_SUM_ESCAPED, ph.e1);
     acc.add(RT_SUM_BOUNDARY, ph.b);
-    const double t = ph.p0 - ph.e1 + ph.b;
+    const double t = shell ? ph.dep : ph.p0 - ph.e1 + ph.b;
     acc.add(RT_SUM_TRANSFER_SQ, t * t);
     acc.add(RT_SUM_TRANSFER_P0, t * ph.p0);
     acc.add(RT_SUM_P0_SQ, ph.p0 * ph.p0);
@@ -451,6 +521,7 @@ __device__ __forceinline__ void start_photon(Photon& ph, AccT& acc) {
     ph.p0 = ph.mu * ph.wh;
     ph.e1 = 0.0;
     ph.b = 0.0;
+    ph.dep = 0.0;
     ph.iter = 0u;
     ph.n_scatter = 0;
     acc.add(RT_SUM_INITIAL, ph.p0);

@@ -300,7 +300,7 @@ __global__ __launch_bounds__(kWalkBlock) void walk_kernel(const Cfg cfg0, const 
                     fate = fly<FAST>(cfg, ph, u_step, u_abs, 2, false, acc, hist, reemit, n_used);
                 }
                 if (fate != 0) {
-                    retire(cfg, ph, fate, acc, hist);
+                    retire(cfg, ph, fate, acc, hist, !FAST && cfg.geometry == RT_GEOM_SHELL);
                     alive = false;
                 }
             }

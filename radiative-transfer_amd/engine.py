@@ -68,11 +68,20 @@ class SweepResult:
         s = self.sums
         return (s[:, abi.SUM_INITIAL] - s[:, abi.SUM_ESCAPED] + s[:, abi.SUM_BOUNDARY]) / s[:, abi.SUM_INITIAL]
 
-    def momentum_fraction_sigma(self):
-        """One-sigma statistical error of momentum_fraction (ratio estimator over photons)."""
+    def deposited_fraction(self):
+        """Momentum given to the dust at the collisions / initial momentum (RT_SUM_DUST_MOMENTUM): the reference's
+        commented-out second estimator (MC code.py:773-776).  In the slab with a reflecting face it equals
+        (initial - escaped - escaped_uncounted + 2 boundary) / initial, one boundary term more than
+        momentum_fraction().  In a shell (RT_GEOM_SHELL) it is THE result: radial momentum is not conserved along a
+        straight flight, so a balance of initial, escaped and boundary momentum does not apply."""
+        return self.sums[:, abi.SUM_DUST_MOMENTUM] / self.sums[:, abi.SUM_INITIAL]
+
+    def momentum_fraction_sigma(self, shell=False):
+        """One-sigma statistical error of momentum_fraction (ratio estimator over photons); with `shell`, of
+        deposited_fraction() of a shell sweep (whose per-photon terms are the deposited momenta)."""
         s = self.sums
         n = self.counts[:, abi.CNT_PHOTONS].astype(float)
-        m = self.momentum_fraction()
+        m = self.deposited_fraction() if shell else self.momentum_fraction()
         resid = s[:, abi.SUM_TRANSFER_SQ] - 2 * m * s[:, abi.SUM_TRANSFER_P0] + m * m * s[:, abi.SUM_P0_SQ]
         with np.errstate(invalid="ignore", divide="ignore"):
             var = np.maximum(resid, 0.0) * n / np.maximum(n - 1, 1) / s[:, abi.SUM_INITIAL] ** 2
@@ -81,9 +90,14 @@ class SweepResult:
 
 def make_params(tau, n_photons, *, boundary="reflect", scatter="hg", order="mc", rand_mu=0, abs_only=0,
                 n_mu_bins=10, n_depth_bins=0, max_events=0, n_slabs=8, rank=0, world=1, seed=DEFAULT_SEED,
-                photon_id_base=0, monochromatic=0.0, alpha=0.3, h=H_PLANCK, rng="philox52", table_of_atm=None):
+                photon_id_base=0, monochromatic=0.0, alpha=0.3, h=H_PLANCK, rng="philox52", table_of_atm=None,
+                geometry="slab", shell_inner=0.0):
     """rng: "philox52" (default; 52-bit uniforms, two Philox blocks per loop iteration) or "philox32x4" (one
-    block per iteration, 32-bit uniforms; faster, see rt_rng_mode in include/rt_amd.h)."""
+    block per iteration, 32-bit uniforms; faster, see rt_rng_mode in include/rt_amd.h).
+    geometry: "slab" (the reference's) or "shell", a uniform spherical shell whose inner radius is `shell_inner`
+    thicknesses (see RT_GEOM_SHELL in include/rt_amd.h; use SweepResult.deposited_fraction() for its result)."""
+    if geometry not in abi.GEOMETRY:
+        raise ValueError(f"geometry must be one of {sorted(abi.GEOMETRY)}")
     if rng not in abi.RNG:
         raise ValueError(f"rng must be one of {sorted(abi.RNG)}")
     if boundary not in abi.BOUNDARY:
@@ -96,7 +110,7 @@ def make_params(tau, n_photons, *, boundary="reflect", scatter="hg", order="mc",
     p = abi.RtParams(len(tau), abi.BOUNDARY[boundary], abi.SCATTER[scatter], abi.ORDER[order], int(rand_mu),
                      int(abs_only), int(n_mu_bins), int(n_depth_bins), int(max_events), int(n_slabs), int(rank),
                      int(world), int(seed), int(photon_id_base), float(monochromatic), float(alpha), float(h),
-                     _dp(tau), _u64p(npn), abi.RNG[rng], 0, None)
+                     _dp(tau), _u64p(npn), abi.RNG[rng], abi.GEOMETRY[geometry], None, float(shell_inner))
     p._keep = (tau, npn)
     if table_of_atm is not None:  # which of the tables given to Engine.set_tables (2-D columns) each atmosphere uses
         tab = np.ascontiguousarray(np.broadcast_to(np.atleast_1d(table_of_atm), tau.shape), dtype=np.int32)

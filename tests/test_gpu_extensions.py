@@ -1,0 +1,115 @@
+"""GPU parity of the two modes without a counterpart in the reference (exact Draine sampler, spherical shell)
+against the CPU restatement on the same Philox streams -- integer tallies exact, sums to 1e-12 -- plus their
+closed-form anchors at sizes only the GPU reaches.  tests/test_oracle_extensions.py checks the restatement
+itself against the same anchors."""
+import numpy as np
+import pytest
+from scipy import integrate
+
+from test_gpu_walk import compare, small_table
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("order", ["gray", "mc"])
+def test_draine_exact_matches_oracle(rt, engine, c_oracle, order):
+    wl, g, alb, scale, pdf = small_table()
+    g = g.copy()
+    g[3] = 0.0                       # the isotropic limit of the candidate
+    engine.set_tables(wl, g, alb, scale, pdf)
+    tau = np.array([0.05, 1.0, 6.0])
+    kw = dict(order=order, scatter="draine_exact", alpha=0.3, n_mu_bins=10, boundary="reflect")
+    res = engine.run(rt.make_params(tau, 8000, **kw))
+    ref = c_oracle.run(c_oracle.make_params(tau, 8000, **kw), wl, g, alb, scale, pdf)
+    compare(res, ref, rt._abi)
+
+
+def test_draine_exact_with_alpha_zero_is_henyey_greenstein(rt, engine):
+    """alpha = 0 accepts every candidate: the same law as 'hg' from other draws of the stream."""
+    engine.set_tables([1.0], [0.6], [0.85], [1.0])
+    tau = np.logspace(-1, 1.5, 6)
+    n = 2000000
+    a = engine.run(rt.make_params(tau, n, scatter="hg"))
+    b = engine.run(rt.make_params(tau, n, scatter="draine_exact", alpha=0.0))
+    sig = np.hypot(a.momentum_fraction_sigma(), b.momentum_fraction_sigma())
+    assert np.all(np.abs(a.momentum_fraction() - b.momentum_fraction()) < 4.5 * sig)
+    c = engine.run(rt.make_params(tau, n, scatter="draine_exact", alpha=1.0))    # and alpha matters
+    assert np.any(np.abs(a.momentum_fraction() - c.momentum_fraction()) > 6 * sig)
+
+
+@pytest.mark.parametrize("boundary", ["reflect", "absorb", "reemit"])
+@pytest.mark.parametrize("scatter", ["hg", "iso", "draine_exact"])
+def test_shell_matches_oracle(rt, engine, c_oracle, boundary, scatter):
+    wl, g, alb, scale, pdf = small_table()
+    engine.set_tables(wl, g, alb, scale, pdf)
+    tau = np.array([1e-3, 0.3, 2.0, 20.0])
+    kw = dict(boundary=boundary, scatter=scatter, n_mu_bins=10, rand_mu=(boundary == "reemit"), geometry="shell",
+              shell_inner=0.7, n_depth_bins=8)
+    res = engine.run(rt.make_params(tau, 6000, **kw))
+    ref = c_oracle.run(c_oracle.make_params(tau, 6000, **kw), wl, g, alb, scale, pdf)
+    compare(res, ref, rt._abi, nd=8)
+
+
+@pytest.mark.parametrize("x", [0.02, 50.0, 1e7])
+def test_shell_radii_match_oracle(rt, engine, c_oracle, x):
+    engine.set_tables([1.0], [0.5], [0.9], [1.0])
+    tau = np.logspace(-2, 2, 6)
+    kw = dict(order="gray", h=1.0, geometry="shell", shell_inner=x, n_mu_bins=10)
+    res = engine.run(rt.make_params(tau, 10000, **kw))
+    ref = c_oracle.run(c_oracle.make_params(tau, 10000, **kw), [1.0], [0.5], [0.9], [1.0])
+    compare(res, ref, rt._abi)
+
+
+def test_shell_chord_integral_at_scale(rt, engine):
+    """Pure absorption from an isotropically emitting inner surface: the escape fraction is the chord integral
+    int_0^1 exp(-L(mu)) dmu, L = -r_in mu + sqrt(r_in^2 mu^2 + r_out^2 - r_in^2), here to 4.5 sigma of 2e7 photons."""
+    A = rt._abi
+    engine.set_tables([1.0], [0.5], [0.5], [1.0])
+    n = 20000000
+    xs, taus = np.array([0.05, 1.0, 20.0, 0.3]), np.array([1.0, 0.7, 2.0, 5.0])
+    for x, tau in zip(xs, taus):
+        res = engine.run(rt.make_params([tau], n, geometry="shell", shell_inner=float(x), abs_only=1, rand_mu=1))
+        rin, rout = x * tau, (x + 1) * tau
+        p = integrate.quad(lambda m: np.exp(rin * m - np.sqrt(rin * rin * m * m + rout * rout - rin * rin)), 0, 1,
+                           epsabs=1e-13, epsrel=1e-13)[0]
+        got = res.counts[0, A.CNT_ESCAPED] / n
+        assert abs(got - p) < 4.5 * np.sqrt(p * (1 - p) / n), (x, tau, got, p)
+        assert res.counts[0, A.CNT_BOUNDARY_HITS] == 0
+
+
+def test_shell_limit_and_curvature(rt, engine):
+    """A shell of huge radius deposits what the reflecting slab's collisions deposit (same streams); a strongly
+    curved one (cavity much smaller than the shell is thick) deposits MORE at the same radial optical depth with
+    fewer scatterings: a straight flight turns a sideways photon towards the local radial direction, so the
+    next collision takes more radial momentum from it than in the slab."""
+    A = rt._abi
+    wl, g, alb, scale, pdf = small_table()
+    engine.set_tables(wl, g, alb, scale, pdf)
+    tau = np.logspace(-1, 1.5, 8)
+    n = 1000000
+    flat = engine.run(rt.make_params(tau, n, order="gray", h=1.0))
+    big = engine.run(rt.make_params(tau, n, order="gray", h=1.0, geometry="shell", shell_inner=1e9))
+    np.testing.assert_allclose(big.deposited_fraction(), flat.deposited_fraction(), rtol=0, atol=1e-4)
+    assert np.all(np.abs(big.counts[:, A.CNT_ESCAPED].astype(float) - flat.counts[:, A.CNT_ESCAPED]) <= 20)
+    small = engine.run(rt.make_params(tau, n, order="gray", h=1.0, geometry="shell", shell_inner=0.05))
+    sig = small.momentum_fraction_sigma(shell=True)
+    assert np.all(sig > 0) and np.all(sig < 5e-3)
+    assert np.all(small.deposited_fraction()[3:] > big.deposited_fraction()[3:] + 10 * sig[3:])
+    assert small.counts[:, A.CNT_SCATTER].sum() < big.counts[:, A.CNT_SCATTER].sum()
+    # energy is conserved whatever the geometry: every photon ends absorbed or outside
+    c = small.counts
+    assert np.array_equal(c[:, A.CNT_ESCAPED] + c[:, A.CNT_ABSORBED] + c[:, A.CNT_GUARD], c[:, A.CNT_PHOTONS])
+    rerun = engine.run(rt.make_params(tau, n, order="gray", h=1.0, geometry="shell", shell_inner=0.05))
+    assert np.array_equal(rerun.sums, small.sums) and np.array_equal(rerun.counts, small.counts)
+
+
+def test_extension_errors(rt, engine):
+    engine.set_tables([0.5], [0.5], [0.5], [1.0])
+    with pytest.raises(rt.RtError):
+        engine.run(rt.make_params(1.0, 100, geometry="shell", shell_inner=0.0))
+    with pytest.raises(rt.RtError):
+        engine.run(rt.make_params(1.0, 100, scatter="draine_exact", alpha=1.5))
+    with pytest.raises(rt.RtError):
+        engine.run(rt.make_params(1.0, 100, scatter="draine_exact", rng="philox32x4"))
+    with pytest.raises(ValueError):
+        rt.make_params(1.0, 100, geometry="cylinder")
