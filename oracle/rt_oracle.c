@@ -250,9 +250,10 @@ static void walk_one(const rt_params* p, double tau, const tables_t* t, stream_t
             double rin = p->shell_inner * zmax, r = rin + z;
             int reemitted = 0;
             if (mu < 0) {
-                double d2 = rin * rin - r * r * (1 - mu * mu);
+                double sin2 = 1 - mu * mu;
+                double d2 = rin * rin - r * r * sin2;
                 if (d2 > 0) {
-                    double half = sqrt(d2), d_in = -r * mu - half;
+                    double half = sin2 == 0 ? rin : sqrt(d2), d_in = -r * mu - half;
                     if (d_in < 0) d_in = 0;
                     if (path >= d_in) {
                         double mu_c = half / rin;
@@ -277,7 +278,10 @@ static void walk_one(const rt_params* p, double tau, const tables_t* t, stream_t
                     }
                 }
             }
-            if (!reemitted) {
+            if (!reemitted && 1 - mu * mu == 0) { /* radial flight, exact */
+                z = z + path * mu;
+                if (z < 0) z = 0;
+            } else if (!reemitted) {
                 double q = path * (path + 2 * r * mu), r2 = sqrt(r * r + q);
                 double m2 = (r * mu + path) / r2;
                 mu = m2 > 1 ? 1 : (m2 < -1 ? -1 : m2);

@@ -284,9 +284,10 @@ __device__ __forceinline__ int fly_shell(const Cfg& cfg, Photon& ph, double path
     const double rin = cfg.shell_inner * ph.zmax;
     double r = rin + ph.z;
     if (ph.mu < 0.0) {
-        const double d2 = rin * rin - r * r * (1.0 - ph.mu * ph.mu);  // r_in^2 - (impact parameter)^2
+        const double sin2 = 1.0 - ph.mu * ph.mu;
+        const double d2 = rin * rin - r * r * sin2;  // r_in^2 - (impact parameter)^2
         if (d2 > 0.0) {
-            const double half = sqrt(d2);  // half the chord through the cavity
+            const double half = sin2 == 0.0 ? rin : sqrt(d2);  // half the chord through the cavity
             double d_in = -r * ph.mu - half;
             d_in = d_in > 0.0 ? d_in : 0.0;
             if (path >= d_in) {
@@ -309,6 +310,11 @@ __device__ __forceinline__ int fly_shell(const Cfg& cfg, Photon& ph, double path
                 }
             }
         }
+    }
+    if (1.0 - ph.mu * ph.mu == 0.0) {  // a radial photon stays radial, exactly (most photons before their first collision)
+        const double z = ph.z + path * ph.mu;
+        ph.z = z > 0.0 ? z : 0.0;
+        return 0;
     }
     const double q = path * (path + 2.0 * r * ph.mu);  // r'^2 - r^2
     const double r2 = sqrt(r * r + q);

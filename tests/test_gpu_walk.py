@@ -21,12 +21,12 @@ def small_table(n=64):
     return wl, g, alb, scale, pdf
 
 
-def compare(res, ref, A, nd=0):
+def compare(res, ref, A, nd=0, rtol=RTOL):
     assert np.array_equal(res.counts, ref.counts)
     assert np.array_equal(res.mu_hist, ref.mu_hist)
     scale = np.abs(ref.sums[:, [A.SUM_INITIAL]])
-    np.testing.assert_allclose(res.sums, ref.sums, rtol=RTOL, atol=0)
-    np.testing.assert_allclose(res.slab_sums, ref.slab_sums, rtol=RTOL, atol=0)
+    np.testing.assert_allclose(res.sums, ref.sums, rtol=rtol, atol=0)
+    np.testing.assert_allclose(res.slab_sums, ref.slab_sums, rtol=rtol, atol=0)
     if nd:
         for got, want in ((res.depth_momentum, ref.depth_momentum), (res.depth_energy, ref.depth_energy)):
             assert np.all(np.abs(got - want) <= 1e-11 * np.abs(want) + 1e-13 * scale), np.abs(got - want).max()
