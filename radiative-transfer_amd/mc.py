@@ -87,15 +87,17 @@ def _tables_for(PDF, Range, Grain_data, monochromatic):
 
 def run_sweep(tau_list, num_photons, boundary, scatter, PDF, Range, Grain_data, *, rand_mu=False, abs_only=False,
               monochromatic=0, h=H_PLANCK, order="mc", seed=DEFAULT_SEED, photon_id_base=0, n_mu_bins=10,
-              n_depth_bins=0, max_events=0, alpha=0.3, engine=None):
-    """All atmospheres of tau_list in one kernel launch; returns the engine's SweepResult."""
+              n_depth_bins=0, max_events=0, alpha=0.3, geometry="slab", shell_inner=0.0, engine=None):
+    """All atmospheres of tau_list in one kernel launch; returns the engine's SweepResult.
+    scatter may also be 'draine_exact' and geometry 'shell' (extensions, see include/rt_amd.h)."""
     eng = engine or default_engine()
     wl, g, alb, sc, pdf = _tables_for(PDF, Range, Grain_data, monochromatic)
     eng.set_tables(wl, g, alb, sc, pdf)
     prm = make_params(tau_list, num_photons, boundary=boundary, scatter=scatter, order=order, rand_mu=int(bool(rand_mu)),
                       abs_only=int(bool(abs_only)), n_mu_bins=n_mu_bins, n_depth_bins=n_depth_bins,
                       max_events=max_events, seed=seed, photon_id_base=photon_id_base,
-                      monochromatic=float(monochromatic) if monochromatic else 0.0, alpha=alpha, h=h)
+                      monochromatic=float(monochromatic) if monochromatic else 0.0, alpha=alpha, h=h,
+                      geometry=geometry, shell_inner=shell_inner)
     return eng.run(prm)
 
 
@@ -212,7 +214,8 @@ def write_deposition_csv(path, tau_list, result, h_g=None):
 def runMC(BPASS_file, time_slice, num_photons, Range, Grain_data, momentum_method_1, photon_reduction=0,
           boundary="reflect", scatter="hg", save_MC=False, *, sed=None, tau_list=None, min_tau=10 ** -3, max_tau=100,
           wl_min=0.001, wl_max=10, grain_type="mix", rand_mu=False, abs_only=False, monochromatic=0, h=H_PLANCK,
-          seed=DEFAULT_SEED, n_depth_bins=0, out_dir=".", engine=None, return_result=False):
+          seed=DEFAULT_SEED, n_depth_bins=0, out_dir=".", engine=None, return_result=False, alpha=0.3,
+          geometry="slab", shell_inner=0.0):
     """MC code.py:992.  Runs every atmosphere of tau_list inside [min_tau, max_tau], fills the caller's
     ``momentum_method_1`` in place and returns ``momentum_transfer`` over the whole tau_list.
 
@@ -220,7 +223,11 @@ def runMC(BPASS_file, time_slice, num_photons, Range, Grain_data, momentum_metho
     None, column str(time_slice) of the BPASS text file ``BPASS_file`` (wavelengths in Angstrom, cut to
     [wl_min, wl_max] microns as at MC code.py:1017-1020; ``Range`` is then taken from the file).
     With ``save_MC`` the column str(time_slice) of 'detailed MC {grain_type} {BPASS name}csv' in
-    ``out_dir`` is written (created if absent)."""
+    ``out_dir`` is written (created if absent).
+
+    Extensions: scatter='draine_exact' (with ``alpha``) and geometry='shell' with ``shell_inner`` = inner radius /
+    thickness; for a shell the curve is the momentum deposited at the collisions over the initial momentum
+    (SweepResult.deposited_fraction) instead of the slab's (initial - escaped + boundary) / initial."""
     tau_list = np.logspace(-3, 2, 100, base=10) if tau_list is None else np.asarray(tau_list, dtype=float)
     tau_list_calc = tau_list[(tau_list >= min_tau) & (tau_list <= max_tau)]   # MC code.py:74
     if sed is None:
@@ -233,8 +240,9 @@ def runMC(BPASS_file, time_slice, num_photons, Range, Grain_data, momentum_metho
     counts = photon_reduction_counts(num_photons, photon_reduction, len(tau_list_calc))
     res = run_sweep(tau_list_calc, counts, boundary, scatter, PDF, Range, Grain_data, rand_mu=rand_mu,
                     abs_only=abs_only, monochromatic=monochromatic, h=h, seed=seed, n_depth_bins=n_depth_bins,
-                    engine=engine)
-    momentum_method_1[:len(tau_list_calc)] = res.momentum_fraction()          # MC code.py:1062
+                    alpha=alpha, geometry=geometry, shell_inner=shell_inner, engine=engine)
+    momentum_method_1[:len(tau_list_calc)] = (res.deposited_fraction() if geometry == "shell"
+                                              else res.momentum_fraction())      # MC code.py:1062
     momentum_transfer = extrapolate(tau_list, tau_list_calc, np.asarray(momentum_method_1[:len(tau_list_calc)]),
                                     min_tau, max_tau)
     if save_MC:

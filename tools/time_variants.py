@@ -15,12 +15,14 @@ eng = rt.Engine(0)
 eng.set_tables(cfg["wl"], cfg["g"], cfg["albedo"], cfg["scale"], cfg["pdf"])
 A = rt._abi
 for kw in (dict(), dict(boundary="absorb"), dict(boundary="reemit"), dict(scatter="iso"), dict(order="gray", h=1.0),
-           dict(n_depth_bins=32), dict(rand_mu=1), dict(abs_only=1)):
+           dict(n_depth_bins=32), dict(rand_mu=1), dict(abs_only=1), dict(scatter="draine_exact", alpha=0.3),
+           dict(geometry="shell", shell_inner=1.0), dict(geometry="shell", shell_inner=0.05, n_depth_bins=32),
+           dict(geometry="shell", shell_inner=1.0, scatter="draine_exact", alpha=0.3)):
     prm = rt.make_params(cfg["tau_list"], n, **({"h": cfg["h"]} | kw))
     eng.run(prm)
     eng.kernel_time(reset=True)
     res = eng.run(prm)
     ms, _ = eng.kernel_time()
     ev, fl = int(res.counts[:, A.CNT_SCATTER].sum()), int(res.counts[:, A.CNT_FLIGHTS].sum())
-    print(f"{str(kw):32s} kernel {ms:8.3f} ms  flights {fl:.3e}  events {ev:.3e}  {fl / ms / 1e6:.1f} Gflights/s  {ev / ms / 1e6:.1f} Gevents/s")
+    print(f"{str(kw):72s} kernel {ms:8.3f} ms  flights {fl:.3e}  events {ev:.3e}  {fl / ms / 1e6:.1f} Gflights/s  {ev / ms / 1e6:.1f} Gevents/s")
 eng.close()
