@@ -353,9 +353,10 @@ static void walk_one(const rt_params* p, double tau, const tables_t* t, stream_t
         if (!draw(s, &u_phi)) { fate = RT_FATE_GUARD; break; }
         if ((p->scatter == RT_SCATTER_DRAINE || p->scatter == RT_SCATTER_DRAINE_EXACT) && !iso) {
             /* draws are consumed in aligned pairs: the partner of the azimuth draw is skipped */
-            int ok = draw(s, &u_s);
+            int ok = draw(s, &u_s), tries = 0;
             while (ok) {
                 double y, cnd;
+                if (tries++ >= 4096) { ok = 0; break; } /* the device's bound on the rejection loop */
                 if (!draw(s, &y) || !draw(s, &cnd)) { ok = 0; break; }
                 cnd = 2 * cnd - 1;
                 if (p->scatter == RT_SCATTER_DRAINE) {

@@ -265,6 +265,8 @@ __device__ __forceinline__ int depth_bin(const Cfg& cfg, const Photon& ph) {
     return k >= cfg.n_depth_bins ? cfg.n_depth_bins - 1 : k;
 }
 
+constexpr int kMaxDraineTries = 4096;
+
 __device__ __forceinline__ double draine_pdf(double g, double alpha, double m) {
     // Numpy_random_walk.py:124.  The power 3/2 is taken as d*sqrt(d): within 2 ulp of pow(d, 1.5), which only
     // matters to the acceptance test pdf > y when the two agree to 16 digits, and it keeps the general pow
@@ -426,7 +428,10 @@ __device__ __forceinline__ int scatter(const Cfg& cfg, Photon& ph, Src& src, dou
     if (!FAST && (law == RT_SCATTER_DRAINE || law == RT_SCATTER_DRAINE_EXACT) && !iso) {
         mu_prime = 0.0;
         bool ok = false;
-        for (;;) {  // rejection sampling of the Draine phase function, one pair (y, candidate) per try
+        // rejection sampling of the Draine phase function, one pair (y, candidate) per try.  The bound only ends
+        // a loop that could not end otherwise (a NaN asymmetry parameter accepts nothing); the slowest legitimate
+        // case, the reference's sampler at g = 0.85, accepts 8 % of its tries.
+        for (int tries = 0; tries < kMaxDraineTries; ++tries) {
             double y, cand;
             const int av = src.pair(y, cand);
             if (Src::kBounded && av < 2) break;

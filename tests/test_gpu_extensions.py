@@ -129,3 +129,19 @@ def test_runmc_in_a_shell(rt, engine):
                         geometry="shell", shell_inner=0.5, scatter="draine_exact", alpha=0.3, return_result=True)
     np.testing.assert_array_equal(out, res.deposited_fraction())
     assert np.all(np.diff(out[:8]) > 0) and 0 < out[0] < 2e-3 and out[-1] > 1
+
+
+@pytest.mark.parametrize("scatter", ["draine", "draine_exact"])
+def test_rejection_loop_is_bounded(rt, engine, c_oracle, scatter):
+    """A NaN asymmetry parameter accepts no candidate: the loop gives up after its bound and the photon is
+    retired by the guard, on the device as in the restatement."""
+    A = rt._abi
+    tab = ([1.0], [float("nan")], [0.9], [1.0])
+    engine.set_tables(*tab)
+    kw = dict(order="gray", h=1.0, scatter=scatter, alpha=0.3)
+    res = engine.run(rt.make_params([2.0], 2000, **kw))
+    ref = c_oracle.run(c_oracle.make_params([2.0], 2000, **kw), *tab)
+    assert np.array_equal(res.counts, ref.counts)
+    c = res.counts[0]
+    assert c[A.CNT_GUARD] > 0 and c[A.CNT_SCATTER] == 0
+    assert c[A.CNT_GUARD] + c[A.CNT_ESCAPED] + c[A.CNT_ABSORBED] == 2000
