@@ -71,6 +71,7 @@ struct rt_ctx {
     std::vector<double> wl;
     DevBuf<rt::TableRec> d_rec;
     DevBuf<rt::AliasEntry> d_alias;
+    DevBuf<double> d_lam;
     DevBuf<rt::LogTableEntry> d_log_table;
     // sweep workspace
     DevBuf<rt::AtmPlan> d_plan;
@@ -144,6 +145,7 @@ rt::Cfg make_cfg(const rt_ctx* ctx, const rt_params* p) {
     c.id_base = p->photon_id_base;
     c.rec = ctx->d_rec.p;
     c.alias = ctx->d_alias.p;
+    c.lam = ctx->d_lam.p;
     c.n_wl = ctx->n_wl;
     c.mono_index = -1;
     c.log_table = ctx->d_log_table.p;
@@ -253,6 +255,7 @@ int rt_destroy(rt_ctx* ctx) {
     }
     ctx->d_rec.release();
     ctx->d_alias.release();
+    ctx->d_lam.release();
     ctx->d_log_table.release();
     ctx->d_plan.release();
     ctx->d_prefix.release();
@@ -297,7 +300,7 @@ int rt_set_tables_multi(rt_ctx* ctx, int32_t n_tables, int32_t n_wl, const doubl
         const size_t o = (size_t)t * n;
         double total = 0.0;
         for (int i = 0; i < n_wl; ++i) {
-            rec[o + i] = {wl[i], g[o + i], albedo[o + i], scale[o + i], 1.0 / wl[i], 1.0 / (2.0 * g[o + i])};
+            rec[o + i] = {g[o + i], albedo[o + i], scale[o + i], 1.0 / wl[i]};
             double p = pdf ? pdf[o + i] : 1.0;
             if (!(p > 0.0)) p = 0.0;  // also maps NaN to 0
             if (p > 1.0) p = 1.0;     // AcceptReject accepts with probability min(PDF, 1)
@@ -332,6 +335,8 @@ int rt_set_tables_multi(rt_ctx* ctx, int32_t n_tables, int32_t n_wl, const doubl
     RT_HIP(hipStreamSynchronize(ctx->stream));
     RT_HIP(hipMemcpy(ctx->d_rec.p, rec.data(), sizeof(rt::TableRec) * total_n, hipMemcpyHostToDevice));
     RT_HIP(hipMemcpy(ctx->d_alias.p, alias.data(), sizeof(rt::AliasEntry) * total_n, hipMemcpyHostToDevice));
+    RT_HIP(ctx->d_lam.reserve(n));
+    RT_HIP(hipMemcpy(ctx->d_lam.p, wl, sizeof(double) * n, hipMemcpyHostToDevice));
     ctx->n_wl = n_wl;
     ctx->n_tables = n_tables;
     ctx->wl.assign(wl, wl + n_wl);

@@ -76,12 +76,15 @@ __device__ __forceinline__ double u52(uint32_t a, uint32_t b) {
 // Uniform in (0,1) from one word: (w + 1/2) / 2^32, exact in fp64 (RT_RNG_PHILOX32X4).
 __device__ __forceinline__ double u32mid(uint32_t w) { return fma((double)w, 0x1p-32, 0x1p-33); }
 
-struct TableRec {  // one wavelength: what CreatePhotons copies into a photon row (MC code.py:403-408), with
-                   // the two per-photon quotients GetZMomentum and HGScatter form on every call, 1/lambda and
-                   // 1/(2*g) (MC code.py:367, :439), taken once on the host (IEEE division, as NumPy's)
-    double lam, g, albedo, scale, inv_lam, inv2g;
+struct TableRec {  // one wavelength: what CreatePhotons copies into a photon row (MC code.py:403-408), with the
+                   // quotient GetZMomentum forms on every call, 1/lambda (MC code.py:367), taken once on the
+                   // host (IEEE division, as NumPy's).  32 bytes: two 16-byte loads, and a record never
+                   // straddles a 128-byte cache line (a 48-byte record with 1/(2g) stored as well did one time
+                   // in four, and the extra misses cost more than the division does).  lambda itself, which only
+                   // the gray loop order weights by, lives in Cfg::lam.
+    double g, albedo, scale, inv_lam;
 };
-static_assert(sizeof(TableRec) == 48, "three 16-byte loads per record");
+static_assert(sizeof(TableRec) == 32, "two 16-byte loads per record");
 
 // Walker/Vose alias table of the emission law: bucket i (one per wavelength) keeps wavelength i with
 // probability `prob` and hands the rest of its 1/n share to wavelength `alias`.  One 16-byte load and no
@@ -104,6 +107,7 @@ struct Cfg {
     // emission tables
     const TableRec* rec;
     const AliasEntry* alias;  // n_wl entries
+    const double* lam;        // n_wl wavelengths (shared by all tables); read in the gray loop order only
     int32_t n_wl, mono_index;
     int32_t table_base;  // first entry of the current atmosphere's table in rec / alias (several tables back to back)
     const LogTableEntry* log_table;  // kLogTableEntries entries in global memory (copied to LDS per workgroup)
@@ -235,17 +239,21 @@ __device__ __forceinline__ void set_constants(const Cfg& cfg, double tau, double
 }
 
 __device__ __forceinline__ TableRec load_record(const Cfg& cfg, int i) {
-    const double2* p = reinterpret_cast<const double2*>(&cfg.rec[i]);  // three 16-byte loads
-    const double2 a = p[0], b = p[1], c = p[2];
-    return {a.x, a.y, b.x, b.y, c.x, c.y};
+    const double2* p = reinterpret_cast<const double2*>(&cfg.rec[i]);  // two 16-byte loads
+    const double2 a = p[0], b = p[1];
+    return {a.x, a.y, b.x, b.y};
 }
 
-__device__ __forceinline__ void set_constants(const Cfg& cfg, double tau, const TableRec& r, double mu0, Photon& ph) {
-    ph.wh = (cfg.order == RT_ORDER_GRAY ? r.lam : r.inv_lam) * cfg.h;
+// `local` is the record's index inside its table (the wavelength index).
+template <bool FAST>
+__device__ __forceinline__ void set_constants(const Cfg& cfg, double tau, const TableRec& r, int local, double mu0,
+                                              Photon& ph) {
+    const double w = (!FAST && cfg.order == RT_ORDER_GRAY) ? cfg.lam[local] : r.inv_lam;
+    ph.wh = w * cfg.h;
     ph.g = r.g;
     ph.albedo = r.albedo;
     ph.zmax = tau * r.scale;
-    ph.inv2g = r.inv2g;
+    ph.inv2g = 1.0 / (2.0 * r.g);  // HGScatter's 1/(2*g), MC code.py:439 (IEEE division, as NumPy's)
     ph.opg2 = 1.0 + r.g * r.g;
     ph.omg2 = 1.0 - r.g * r.g;
     ph.z = 0.0;
@@ -255,8 +263,9 @@ __device__ __forceinline__ void set_constants(const Cfg& cfg, double tau, const 
 __device__ __forceinline__ void emit_from_table(const Cfg& cfg, double tau, PhiloxSrc& src, Photon& ph) {
     double ua, ub;
     src.emit_pair(ua, ub);
-    const TableRec r = load_record(cfg, sample_index(cfg, ua));
-    set_constants(cfg, tau, r, cfg.rand_mu ? ub : 1.0, ph);
+    const int i = sample_index(cfg, ua);
+    const TableRec r = load_record(cfg, i);
+    set_constants<false>(cfg, tau, r, i - cfg.table_base, cfg.rand_mu ? ub : 1.0, ph);
 }
 
 __device__ __forceinline__ int depth_bin(const Cfg& cfg, const Photon& ph) {

@@ -273,6 +273,7 @@ __global__ __launch_bounds__(kWalkBlock) void walk_kernel(const Cfg cfg0, const 
                 const double prob = __hiloint2double((int)raw.y, (int)raw.x);
                 int idx = (xb - (double)bucket) < prob ? bucket : (int)raw.z;
                 idx = cfg.mono_index >= 0 ? cfg.mono_index : idx;
+                const int local = fresh ? idx : 0;
                 idx = fresh ? cfg.table_base + idx : 0;
                 const TableRec rec = load_record(cfg, idx);
                 const bool guard = scatter_fate != 0 || (!fresh && ph.iter >= (uint32_t)cfg.max_events);
@@ -289,7 +290,7 @@ __global__ __launch_bounds__(kWalkBlock) void walk_kernel(const Cfg cfg0, const 
                     src.pair(u_step, u_abs);
                 }
                 if (fresh) {
-                    set_constants(cfg, tau, rec, cfg.rand_mu ? ub : 1.0, ph);
+                    set_constants<FAST>(cfg, tau, rec, local, cfg.rand_mu ? ub : 1.0, ph);
                     start_photon(ph, acc);
                     alive = true;
                 }
