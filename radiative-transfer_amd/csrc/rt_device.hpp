@@ -253,7 +253,9 @@ __device__ __forceinline__ void set_constants(const Cfg& cfg, double tau, const 
     ph.g = r.g;
     ph.albedo = r.albedo;
     ph.zmax = tau * r.scale;
-    ph.inv2g = 1.0 / (2.0 * r.g);  // HGScatter's 1/(2*g), MC code.py:439 (IEEE division, as NumPy's)
+    // HGScatter's 1/(2*g), MC code.py:439.  div_unit gives the IEEE quotient for every normal g (tested bit for
+    // bit); g = 0 gives NaN where IEEE gives inf, and the cosine it enters, inf * 0, is NaN either way.
+    ph.inv2g = FAST ? div_unit(1.0, 2.0 * r.g) : 1.0 / (2.0 * r.g);
     ph.opg2 = 1.0 + r.g * r.g;
     ph.omg2 = 1.0 - r.g * r.g;
     ph.z = 0.0;

@@ -156,5 +156,10 @@ def test_device_math_accuracy(engine):
     assert np.array_equal(engine.selftest_math(tiny)[2], np.sqrt(tiny))
     # ... and so is the division of HGScatter's operand ranges
     assert np.array_equal(got_div, (1.0 - u * u) / (2.0 * u))
+    # ... for either sign of the denominator, and for the reciprocal 1 / (2 g) itself (1 - g*g rounds to 1 below 7.4e-9)
+    g = np.concatenate([-u[:100000], np.logspace(-300, -8.2, 20000), -np.logspace(-300, -8.2, 20000)])
+    got = engine.selftest_math(g)[3]
+    assert np.array_equal(got, (1.0 - g * g) / (2.0 * g))
+    assert np.array_equal(got[100000:], 1.0 / (2.0 * g[100000:]))
     lz, _, sz, _ = engine.selftest_math(np.array([0.0]))
     assert np.isneginf(lz[0]) and sz[0] == 0.0

@@ -1,8 +1,8 @@
 #!/bin/bash
-# Memory-path counters for one library variant: bash tools/pmc_mem.sh <variant> <tag>
-V=$1; TAG=$2
+# Memory-path counters of the walk kernel (texture addresser / data return / L1):  bash tools/pmc_mem.sh <tag>
+# RT_AMD_LIB selects another build of the library.
+TAG=${1:-mem}
 OUT=gpurun_out/$TAG; mkdir -p $OUT
-export RT_AMD_LIB=$PWD/radiative-transfer_amd/csrc/variants/$V.so
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 ARGS="--photons 4000000 --steps 1 --warmup 0 --no-cpu"
 pass() { name=$1; shift; timeout -s KILL 180 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/$name" -- python3 bench.py $ARGS > "$OUT/$name.log" 2>&1 || { echo "pass $name failed"; tail -3 "$OUT/$name.log"; return 1; }; echo "pass $name ok"; }
