@@ -255,7 +255,7 @@ __device__ __forceinline__ void set_constants(const Cfg& cfg, double tau, const 
     ph.zmax = tau * r.scale;
     // HGScatter's 1/(2*g), MC code.py:439.  div_unit gives the IEEE quotient for every normal g (tested bit for
     // bit); g = 0 gives NaN where IEEE gives inf, and the cosine it enters, inf * 0, is NaN either way.
-    ph.inv2g = FAST ? div_unit(1.0, 2.0 * r.g) : 1.0 / (2.0 * r.g);
+    ph.inv2g = div_unit(1.0, 2.0 * r.g);
     ph.opg2 = 1.0 + r.g * r.g;
     ph.omg2 = 1.0 - r.g * r.g;
     ph.z = 0.0;
