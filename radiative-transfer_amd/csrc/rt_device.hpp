@@ -160,6 +160,7 @@ struct Hist {
     double* depth_mom;
     double* depth_en;
     const LogTableEntry* log_table;
+    const double* coef;  // LDS copy of math_coef(0..kMathCoefs-1), or null (kernels that keep them in registers)
 };
 
 // ---------------------------------------------------------------------------
@@ -348,9 +349,11 @@ __device__ __forceinline__ int fly_shell(const Cfg& cfg, Photon& ph, double path
 // FAST fixes (RT_ORDER_MC, reflect, hg, no depth bins, abs_only off) at compile time; the
 // generic form reads cfg.  `reemit` is called when a photon is re-emitted at the lower boundary.
 // ---------------------------------------------------------------------------
+// fly() with the optical length of the step, -ln(xi), already formed (a caller that has independent memory
+// requests in flight takes the logarithm first, so that it runs under their latency).
 template <bool FAST, class Reemit, class AccT>
-__device__ __forceinline__ int fly(const Cfg& cfg, Photon& ph, double u_step, double u_abs, int avail, bool bounded,
-                                   AccT& acc, const Hist& hist, Reemit&& reemit, int& n_used) {
+__device__ __forceinline__ int fly_path(const Cfg& cfg, Photon& ph, double path, double u_abs, int avail, bool bounded,
+                                        AccT& acc, const Hist& hist, Reemit&& reemit, int& n_used) {
     const bool gray = FAST ? false : cfg.order == RT_ORDER_GRAY;
     const int boundary = FAST ? (int)RT_BOUNDARY_REFLECT : cfg.boundary;
     const bool depth = FAST ? false : cfg.n_depth_bins > 0;
@@ -362,7 +365,6 @@ __device__ __forceinline__ int fly(const Cfg& cfg, Photon& ph, double u_step, do
     n_used += 1;
 
     // TakeStep
-    const double path = -log_unit(u_step, hist.log_table);
     if (shell) {
         const int f = fly_shell(cfg, ph, path, boundary, acc, reemit);
         if (f != 0) return f;
@@ -419,7 +421,18 @@ __device__ __forceinline__ int fly(const Cfg& cfg, Photon& ph, double u_step, do
     return 0;
 }
 
-template <bool FAST, class Src, class AccT>
+template <bool FAST, class Reemit, class AccT>
+__device__ __forceinline__ int fly(const Cfg& cfg, Photon& ph, double u_step, double u_abs, int avail, bool bounded,
+                                   AccT& acc, const Hist& hist, Reemit&& reemit, int& n_used) {
+    if (bounded && avail < 1) return RT_FATE_GUARD;  // before the logarithm: its argument is not a draw then
+    const double path = -log_unit(u_step, hist.log_table);
+    return fly_path<FAST>(cfg, ph, path, u_abs, avail, bounded, acc, hist, reemit, n_used);
+}
+
+// LEAN (the production walk kernel): the cosine's polynomial coefficients are read from LDS (hist.coef), and 1 + g^2 and
+// 1 - g^2 are formed here from g (the same two operations set_constants performs, so the same values) instead
+// of being carried in ph: fewer registers held across the loop, same results.
+template <bool FAST, bool LEAN = false, class Src, class AccT>
 __device__ __forceinline__ int scatter(const Cfg& cfg, Photon& ph, Src& src, double u_phi, double u_s, int avail2,
                                        AccT& acc, const Hist& hist) {
     const bool gray = FAST ? false : cfg.order == RT_ORDER_GRAY;
@@ -471,8 +484,10 @@ __device__ __forceinline__ int scatter(const Cfg& cfg, Photon& ph, Src& src, dou
             mu_prime = s;
             direct = true;
         } else {
-            const double q = FAST ? div_unit(ph.omg2, 1.0 + ph.g * s) : ph.omg2 / (1.0 + ph.g * s);
-            mu_prime = ph.inv2g * (ph.opg2 - q * q);
+            const double opg2 = LEAN ? 1.0 + ph.g * ph.g : ph.opg2;
+            const double omg2 = LEAN ? 1.0 - ph.g * ph.g : ph.omg2;
+            const double q = FAST ? div_unit(omg2, 1.0 + ph.g * s) : omg2 / (1.0 + ph.g * s);
+            mu_prime = ph.inv2g * (opg2 - q * q);
         }
     }
     // RotateIntoLabFrame
@@ -480,7 +495,8 @@ __device__ __forceinline__ int scatter(const Cfg& cfg, Photon& ph, Src& src, dou
     if (FAST) {
         // The mu == +-1 branches of the reference (MC code.py:605-612) give what the general formula gives
         // there: 1 - mu^2 is exactly 0, so the first term is -(+-0) and the sum is mu' or -mu' exactly.
-        mu_new = -sqrt_unit((1.0 - mu_old * mu_old) * (1.0 - mu_prime * mu_prime)) * cos_2pi(u_phi) + mu_old * mu_prime;
+        const double c = LEAN ? cos_2pi(u_phi, hist.coef) : cos_2pi(u_phi);
+        mu_new = -sqrt_unit((1.0 - mu_old * mu_old) * (1.0 - mu_prime * mu_prime)) * c + mu_old * mu_prime;
     } else if (direct || mu_old == 1.0) {
         mu_new = mu_prime;
     } else if (mu_old == -1.0) {

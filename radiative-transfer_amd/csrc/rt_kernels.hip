@@ -34,20 +34,27 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
 }
 
 constexpr size_t kLogTableBytes = sizeof(LogTableEntry) * kLogTableEntries;
+constexpr size_t kCoefBytes = sizeof(double) * 16;  // kMathCoefs polynomial coefficients, padded
+constexpr size_t kMathLdsBytes = kLogTableBytes + kCoefBytes;
+static_assert(kMathCoefs <= 16, "coefficient block");
 
-// LDS layout per block: the logarithm table (2 KiB), then [waves][2*nd] doubles (depth momentum,
-// depth energy), then [waves][nmu] u32 (escape-cosine histogram).  The histograms are private
-// to a wave; the table is shared and read-only after stage_log_table().
+// LDS layout per block: the logarithm table (2 KiB) and the polynomial coefficients of ln / cos (128 B), then
+// [waves][2*nd] doubles (depth momentum, depth energy), then [waves][nmu] u32 (escape-cosine histogram).
+// The histograms are private to a wave; table and coefficients are shared and read-only after
+// stage_log_table().  The production kernel reads the coefficients from LDS where it uses them: held in
+// registers across the loop they took 28 of its 115 vector registers, without them it fits 5 waves per SIMD
+// instead of 4.
 __device__ __forceinline__ Hist wave_hist(unsigned char* lds_raw, int wave, int nmu, int nd) {
-    double* depth_base = reinterpret_cast<double*>(lds_raw + kLogTableBytes) + (size_t)wave * 2 * nd;
+    double* depth_base = reinterpret_cast<double*>(lds_raw + kMathLdsBytes) + (size_t)wave * 2 * nd;
     uint32_t* mu_base =
-        reinterpret_cast<uint32_t*>(lds_raw + kLogTableBytes + sizeof(double) * (size_t)kWavesPerBlock * 2 * nd) +
+        reinterpret_cast<uint32_t*>(lds_raw + kMathLdsBytes + sizeof(double) * (size_t)kWavesPerBlock * 2 * nd) +
         (size_t)wave * nmu;
     Hist h;
     h.mu = mu_base;
     h.depth_mom = nd ? depth_base : nullptr;
     h.depth_en = nd ? depth_base + nd : nullptr;
     h.log_table = reinterpret_cast<const LogTableEntry*>(lds_raw);
+    h.coef = reinterpret_cast<const double*>(lds_raw + kLogTableBytes);
     return h;
 }
 
@@ -55,6 +62,7 @@ __device__ __forceinline__ Hist wave_hist(unsigned char* lds_raw, int wave, int 
 __device__ __forceinline__ void stage_log_table(const Cfg& cfg, unsigned char* lds_raw) {
     LogTableEntry* dst = reinterpret_cast<LogTableEntry*>(lds_raw);
     for (int k = threadIdx.x; k < kLogTableEntries; k += blockDim.x) dst[k] = cfg.log_table[k];
+    if (threadIdx.x < kMathCoefs) reinterpret_cast<double*>(lds_raw + kLogTableBytes)[threadIdx.x] = math_coef((int)threadIdx.x);
     __syncthreads();
 }
 
@@ -268,7 +276,7 @@ __global__ __launch_bounds__(kWalkBlock) void walk_kernel(const Cfg cfg0, const 
                 int scatter_fate = 0;
                 if (!fresh) {
                     ++src.blk;
-                    scatter_fate = scatter<FAST>(cfg, ph, src, ua, ub, 2, acc, hist);
+                    scatter_fate = scatter<FAST, FAST>(cfg, ph, src, ua, ub, 2, acc, hist);
                 }
                 const double prob = __hiloint2double((int)raw.y, (int)raw.x);
                 int idx = (xb - (double)bucket) < prob ? bucket : (int)raw.z;
@@ -298,7 +306,10 @@ __global__ __launch_bounds__(kWalkBlock) void walk_kernel(const Cfg cfg0, const 
                 if (!guard) {
                     flew = true;
                     int n_used = 0;
-                    fate = fly<FAST>(cfg, ph, u_step, u_abs, 2, false, acc, hist, reemit, n_used);
+                    // FAST: polynomial coefficients from LDS (5 waves per SIMD); the generic kernel is bound by its
+                    // other registers (3 waves per SIMD either way) and keeps them in registers
+                    const double path = FAST ? -log_unit(u_step, hist.log_table, hist.coef) : -log_unit(u_step, hist.log_table);
+                    fate = fly_path<FAST>(cfg, ph, path, u_abs, 2, false, acc, hist, reemit, n_used);
                 }
                 if (fate != 0) {
                     retire(cfg, ph, fate, acc, hist, !FAST && cfg.geometry == RT_GEOM_SHELL);
@@ -521,7 +532,7 @@ hipError_t launch_selftest_math(const LogTableEntry* d_table, long long n, const
 
 size_t walk_lds_bytes(const Cfg& cfg, bool fast) {
     const size_t nd = fast ? 0 : (size_t)cfg.n_depth_bins;
-    return kLogTableBytes + sizeof(double) * kWavesPerBlock * 2 * nd +
+    return kMathLdsBytes + sizeof(double) * kWavesPerBlock * 2 * nd +
            sizeof(uint32_t) * kWavesPerBlock * ((size_t)cfg.n_mu_bins + 1);
 }
 

@@ -61,6 +61,75 @@ __device__ __forceinline__ double log_unit(double x, const LogTableEntry* __rest
     return x == 0.0 ? -__builtin_inf() : res;
 }
 
+// The polynomial coefficients of log_unit and cos_2pi as one array, for kernels that read them from LDS where
+// they are used instead of holding fourteen register pairs of constants across their loop: [0..5] the
+// logarithm's (highest degree first), [6..13] the cosine's.  Same values, same operations, same results.
+constexpr int kMathCoefs = 14;
+__device__ __forceinline__ double math_coef(int k) {
+    switch (k) {
+        case 0: return 1.0 / 7.0;
+        case 1: return -1.0 / 6.0;
+        case 2: return 1.0 / 5.0;
+        case 3: return -1.0 / 4.0;
+        case 4: return 1.0 / 3.0;
+        case 5: return -0.5;
+        case 6: return 4.16639726608991643254e-06;
+        case 7: return -1.04582860367372637990e-04;
+        case 8: return 1.92956265087559594197e-03;
+        case 9: return -2.58068900255420882739e-02;
+        case 10: return 2.35330630272128971114e-01;
+        case 11: return -1.33526276885187988874e+00;
+        case 12: return 4.05871212641673650978e+00;
+        default: return -4.93480220054467899615e+00;
+    }
+}
+
+__device__ __forceinline__ double log_unit(double x, const LogTableEntry* __restrict__ lds_table, const double* lds_coef) {
+    const uint32_t hi = (uint32_t)__double2hiint(x);
+    const uint32_t lo = (uint32_t)__double2loint(x);
+    const int e = (int)(hi >> 20) - 1023;
+    const uint32_t j = (hi >> 13) & 127u;
+    const double m = __hiloint2double((int)((hi & 0x000FFFFFu) | 0x3FF00000u), (int)lo);
+    const LogTableEntry t = lds_table[j];
+    const double2 c01 = *reinterpret_cast<const double2*>(lds_coef);
+    const double2 c23 = *reinterpret_cast<const double2*>(lds_coef + 2);
+    const double2 c45 = *reinterpret_cast<const double2*>(lds_coef + 4);
+    const double r = fma(m, t.inv_c, -1.0);
+    double p = fma_step(r, c01.x, c01.y);
+    p = fma_step(r, p, c23.x);
+    p = fma_step(r, p, c23.y);
+    p = fma_step(r, p, c45.x);
+    p = fma_step(r, p, c45.y);
+    const double r2 = r * r;
+    p = fma(r2, p, r);  // log1p(r)
+    const double ed = (double)e;
+    const double head = fma(ed, 6.93147180369123816490e-01, t.l);  // e * ln2_hi + L[j]
+    const double tail = fma(ed, 1.90821492927058770002e-10, p);    // e * ln2_lo + log1p(r)
+    const double res = head + tail;
+    return x == 0.0 ? -__builtin_inf() : res;
+}
+
+__device__ __forceinline__ double cos_2pi(double u, const double* lds_coef) {
+    const double2 c01 = *reinterpret_cast<const double2*>(lds_coef + 6);
+    const double2 c23 = *reinterpret_cast<const double2*>(lds_coef + 8);
+    const double2 c45 = *reinterpret_cast<const double2*>(lds_coef + 10);
+    const double2 c67 = *reinterpret_cast<const double2*>(lds_coef + 12);
+    const double t = u + u;
+    const double k = rint(t);
+    const double w = t - k;
+    const double z = w * w;
+    double r = fma_step(z, c01.x, c01.y);
+    r = fma_step(z, r, c23.x);
+    r = fma_step(z, r, c23.y);
+    r = fma_step(z, r, c45.x);
+    r = fma_step(z, r, c45.y);
+    r = fma_step(z, r, c67.x);
+    r = fma_step(z, r, c67.y);
+    const double c = fma(z, r, 1.0);
+    const uint32_t sign = (uint32_t)(int)k << 31;  // k odd: negate
+    return __hiloint2double((int)((uint32_t)__double2hiint(c) ^ sign), __double2loint(c));
+}
+
 // ---------------------------------------------------------------------------
 // cos(2*pi*u) for u in [0, 1).  Half-period reduction, exact in u:
 //   t = 2u, k = rint(t) in {0, 1, 2}, w = t - k in [-1/2, 1/2];  cos(2 pi u) = (-1)^k cos(pi w)
