@@ -426,12 +426,20 @@ __global__ void selftest_math_kernel(const LogTableEntry* __restrict__ table, lo
                                      double* __restrict__ out_log, double* __restrict__ out_cos,
                                      double* __restrict__ out_sqrt, double* __restrict__ out_div) {
     __shared__ LogTableEntry lds_table[kLogTableEntries];
+    __shared__ __align__(16) double lds_coef[16];
     for (int k = threadIdx.x; k < kLogTableEntries; k += blockDim.x) lds_table[k] = table[k];
+    if (threadIdx.x < kMathCoefs) lds_coef[threadIdx.x] = math_coef((int)threadIdx.x);
     __syncthreads();
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
-        out_log[i] = log_unit(u[i], lds_table);
-        out_cos[i] = cos_2pi(u[i]);
+        // both forms of each function (coefficients in registers / read from LDS) must agree bit for bit; a
+        // difference is reported as NaN, which no caller's tolerance accepts
+        const double l0 = log_unit(u[i], lds_table), l1 = log_unit(u[i], lds_table, lds_coef);
+        const double c0 = cos_2pi(u[i]), c1 = cos_2pi(u[i], lds_coef);
+        const bool same_l = __double_as_longlong(l0) == __double_as_longlong(l1);
+        const bool same_c = __double_as_longlong(c0) == __double_as_longlong(c1);
+        out_log[i] = same_l ? l0 : __builtin_nan("");
+        out_cos[i] = same_c ? c0 : __builtin_nan("");
         out_sqrt[i] = sqrt_unit(u[i]);
         out_div[i] = div_unit(1.0 - u[i] * u[i], 2.0 * u[i]);
     }
