@@ -442,6 +442,8 @@ int rt_run_device(rt_ctx* ctx, const rt_params* p, void* d_slab_sums, void* d_co
     sw.item_prefix = ctx->d_prefix.p;
     sw.n_atm = (uint32_t)p->n_atm;
     sw.n_items = (uint32_t)items;
+    sw.n_interleaved = 0u;
+    sw.row_len = 0u;
     sw.rank = (uint32_t)p->rank;
     sw.world = (uint32_t)world;
     sw.n_slabs = (uint32_t)n_slabs;
@@ -474,6 +476,15 @@ int rt_run_device(rt_ctx* ctx, const rt_params* p, void* d_slab_sums, void* d_co
     if (grid > need) grid = need;
     if (grid < 1) grid = 1;
 
+    {   // the cheapest items (end of the list) stay in order for the end of the launch: two per resident wave
+        // (measured: 0 costs 2 %, 1 to 8 per wave are equal)
+        const unsigned long long tail = std::min<unsigned long long>(items / 8, (unsigned long long)grid * 4 * 2);
+        const unsigned long long rows = rt::kQueueRows;
+        if (items - tail >= rows * 8) {
+            sw.row_len = (uint32_t)((items - tail) / rows);
+            sw.n_interleaved = (uint32_t)(sw.row_len * rows);
+        }
+    }
     EventPair* ev = nullptr;
     RT_HIP(next_events(ctx, &ev));
     RT_HIP(hipEventRecord(ev->a, stream));

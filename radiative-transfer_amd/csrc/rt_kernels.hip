@@ -112,6 +112,7 @@ __device__ __forceinline__ bool pop_item(const Sweep& sw, unsigned int* d_next, 
     if (lane == 0) q = atomicAdd(d_next, 1u);
     q = __builtin_amdgcn_readfirstlane(q);
     if (q >= sw.n_items) return false;
+    if (q < sw.n_interleaved) q = (q & (kQueueRows - 1u)) * sw.row_len + (q >> kQueueRowsLog2);
     int lo = 0, hi = (int)sw.n_atm;  // sorted position with item_prefix[lo] <= q < item_prefix[lo+1]
     while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;

@@ -30,7 +30,16 @@ struct Sweep {
     uint32_t n_items;
     uint32_t rank, world;
     uint32_t n_slabs, owned_slabs;
+    // Order in which the queue hands out the items of the heaviest-first list: positions below n_interleaved
+    // (= kQueueRows * row_len) go through the list in kQueueRows rows at once, position q -> item
+    // (q % kQueueRows) * row_len + q / kQueueRows, so that thick and thin atmospheres are in flight together
+    // from the first wave to (almost) the last; the remaining items, the cheapest of the list, follow in order
+    // and keep the end of the launch balanced.
+    uint32_t n_interleaved, row_len;
 };
+
+constexpr uint32_t kQueueRowsLog2 = 3;  // measured: 2 to 1024 rows give the same time, 8192 rows 1 % more
+constexpr uint32_t kQueueRows = 1u << kQueueRowsLog2;
 
 constexpr int kWalkBlock = 256;
 
