@@ -70,6 +70,16 @@ __device__ __forceinline__ double u52(uint32_t a, uint32_t b) {
 #endif
 }
 
+// The same draw before the subtraction: m = 1 + u in [1, 2).  Where a uniform only enters an affine expression
+// that one fma evaluates exactly as before -- 2u = 2m - 2 (azimuth), u*n = m*n - n rounded once (emission
+// bucket) -- the production kernel passes m on and saves the subtraction.  (The cosine draw, 2u - 1 = 2m - 3,
+// would need the constant -3 in a register pair, and the kernel has none to spare at 5 waves per SIMD.)
+__device__ __forceinline__ double m52(uint32_t a, uint32_t b) {
+    const uint32_t hi = __builtin_amdgcn_alignbit(0x3FFu, a, 12);
+    const uint32_t lo = __builtin_amdgcn_alignbit(a, b, 12);
+    return __hiloint2double((int)hi, (int)lo);
+}
+
 // ---------------------------------------------------------------------------
 // Run configuration (wave-uniform; passed by value as a kernel argument).
 // ---------------------------------------------------------------------------
@@ -432,7 +442,8 @@ __device__ __forceinline__ int fly(const Cfg& cfg, Photon& ph, double u_step, do
 // LEAN (the production walk kernel): the cosine's polynomial coefficients are read from LDS (hist.coef), and 1 + g^2 and
 // 1 - g^2 are formed here from g (the same two operations set_constants performs, so the same values) instead
 // of being carried in ph: fewer registers held across the loop, same results.
-template <bool FAST, bool LEAN = false, class Src, class AccT>
+// MFORM: u_phi is passed as m = 1 + u (see m52).
+template <bool FAST, bool LEAN = false, bool MFORM = false, class Src, class AccT>
 __device__ __forceinline__ int scatter(const Cfg& cfg, Photon& ph, Src& src, double u_phi, double u_s, int avail2,
                                        AccT& acc, const Hist& hist) {
     const bool gray = FAST ? false : cfg.order == RT_ORDER_GRAY;
@@ -495,7 +506,7 @@ __device__ __forceinline__ int scatter(const Cfg& cfg, Photon& ph, Src& src, dou
     if (FAST) {
         // The mu == +-1 branches of the reference (MC code.py:605-612) give what the general formula gives
         // there: 1 - mu^2 is exactly 0, so the first term is -(+-0) and the sum is mu' or -mu' exactly.
-        const double c = LEAN ? cos_2pi(u_phi, hist.coef) : cos_2pi(u_phi);
+        const double c = LEAN ? cos_2pi<MFORM>(u_phi, hist.coef) : cos_2pi(u_phi);
         mu_new = -sqrt_unit((1.0 - mu_old * mu_old) * (1.0 - mu_prime * mu_prime)) * c + mu_old * mu_prime;
     } else if (direct || mu_old == 1.0) {
         mu_new = mu_prime;

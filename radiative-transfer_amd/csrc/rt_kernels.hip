@@ -266,10 +266,12 @@ __global__ __launch_bounds__(kWalkBlock) void walk_kernel(const Cfg cfg0, const 
                 // (PACKED: the photon's next block serves both, and the flight below as well)
                 const uint32_t block = PACKED ? src.blk : (fresh ? kEmitBlock : src.blk);
                 const PhiloxOut o = philox4x32_10(src.id_lo, src.id_hi, block, src.atm, src.k0, src.k1);
-                const double ua = (!PACKED || fresh) ? u52(o.w0, o.w1) : u32mid(o.w0);
+                // the production kernel keeps its first draw as m = 1 + u (MFORM): both uses are exact affine forms
+                constexpr bool MFORM = FAST && !PACKED;
+                const double ua = MFORM ? m52(o.w0, o.w1) : ((!PACKED || fresh) ? u52(o.w0, o.w1) : u32mid(o.w0));
                 double ub = PACKED ? u32mid(o.w1) : u52(o.w2, o.w3);
                 // alias entry of the new photons' bucket, requested now; scattering lanes read entry 0 (broadcast)
-                const double xb = ua * (double)cfg.n_wl;
+                const double xb = MFORM ? fma(ua, (double)cfg.n_wl, -(double)cfg.n_wl) : ua * (double)cfg.n_wl;
                 int bucket = (int)xb;
                 bucket = bucket < cfg.n_wl ? bucket : cfg.n_wl - 1;
                 bucket = fresh ? bucket : 0;
@@ -277,7 +279,7 @@ __global__ __launch_bounds__(kWalkBlock) void walk_kernel(const Cfg cfg0, const 
                 int scatter_fate = 0;
                 if (!fresh) {
                     ++src.blk;
-                    scatter_fate = scatter<FAST, FAST>(cfg, ph, src, ua, ub, 2, acc, hist);
+                    scatter_fate = scatter<FAST, FAST, MFORM>(cfg, ph, src, ua, ub, 2, acc, hist);
                 }
                 const double prob = __hiloint2double((int)raw.y, (int)raw.x);
                 int idx = (xb - (double)bucket) < prob ? bucket : (int)raw.z;

@@ -109,12 +109,14 @@ __device__ __forceinline__ double log_unit(double x, const LogTableEntry* __rest
     return x == 0.0 ? -__builtin_inf() : res;
 }
 
+// MFORM: the argument is m = 1 + u; 2u = 2m - 2 is exact either way.
+template <bool MFORM = false>
 __device__ __forceinline__ double cos_2pi(double u, const double* lds_coef) {
     const double2 c01 = *reinterpret_cast<const double2*>(lds_coef + 6);
     const double2 c23 = *reinterpret_cast<const double2*>(lds_coef + 8);
     const double2 c45 = *reinterpret_cast<const double2*>(lds_coef + 10);
     const double2 c67 = *reinterpret_cast<const double2*>(lds_coef + 12);
-    const double t = u + u;
+    const double t = MFORM ? fma(2.0, u, -2.0) : u + u;
     const double k = rint(t);
     const double w = t - k;
     const double z = w * w;
