@@ -287,7 +287,8 @@ int rt_set_tables_multi(rt_ctx* ctx, int32_t n_tables, int32_t n_wl, const doubl
     if (!ctx) return fail(RT_ERR_INVALID, "ctx is NULL");
     if (n_tables < 1 || n_wl < 1 || !wl || !g || !albedo || !scale) return fail(RT_ERR_INVALID, "empty or NULL table");
     if (n_wl > (1 << 24)) return fail(RT_ERR_LIMIT, "n_wl %d exceeds 2^24", n_wl);
-    if ((long long)n_tables * n_wl > (1ll << 28)) return fail(RT_ERR_LIMIT, "n_tables * n_wl exceeds 2^28");
+    // the production kernel addresses the records with 32-bit byte offsets (32 bytes per record)
+    if ((long long)n_tables * n_wl > (1ll << 26)) return fail(RT_ERR_LIMIT, "n_tables * n_wl exceeds 2^26");
     RT_HIP(hipSetDevice(ctx->device));
     const size_t n = (size_t)n_wl, total_n = n * (size_t)n_tables;
     std::vector<rt::TableRec> rec(total_n);

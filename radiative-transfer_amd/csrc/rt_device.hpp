@@ -249,6 +249,22 @@ __device__ __forceinline__ void set_constants(const Cfg& cfg, double tau, double
     ph.mu = mu0;
 }
 
+// 16 bytes at base + byte_off as a raw buffer load: the 32-bit offset goes to the instruction as it is, where a
+// global load needs the 64-bit address formed in vector registers first (sign extension, shift, 64-bit add).
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 gather16(const void* base, uint32_t byte_off) {
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, 0, 0);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
+__device__ __forceinline__ TableRec load_record_buffer(const Cfg& cfg, int i) {
+    const uint4 a = gather16(cfg.rec, (uint32_t)i * 32u), b = gather16(cfg.rec, (uint32_t)i * 32u + 16u);
+    return {__hiloint2double((int)a.y, (int)a.x), __hiloint2double((int)a.w, (int)a.z),
+            __hiloint2double((int)b.y, (int)b.x), __hiloint2double((int)b.w, (int)b.z)};
+}
+
 __device__ __forceinline__ TableRec load_record(const Cfg& cfg, int i) {
     const double2* p = reinterpret_cast<const double2*>(&cfg.rec[i]);  // two 16-byte loads
     const double2 a = p[0], b = p[1];

@@ -275,7 +275,8 @@ __global__ __launch_bounds__(kWalkBlock) void walk_kernel(const Cfg cfg0, const 
                 int bucket = (int)xb;
                 bucket = bucket < cfg.n_wl ? bucket : cfg.n_wl - 1;
                 bucket = fresh ? bucket : 0;
-                const uint4 raw = *reinterpret_cast<const uint4*>(&cfg.alias[cfg.table_base + bucket]);
+                const uint4 raw = FAST ? gather16(cfg.alias, (uint32_t)(cfg.table_base + bucket) * 16u)
+                                       : *reinterpret_cast<const uint4*>(&cfg.alias[cfg.table_base + bucket]);
                 int scatter_fate = 0;
                 if (!fresh) {
                     ++src.blk;
@@ -286,7 +287,7 @@ __global__ __launch_bounds__(kWalkBlock) void walk_kernel(const Cfg cfg0, const 
                 idx = cfg.mono_index >= 0 ? cfg.mono_index : idx;
                 const int local = fresh ? idx : 0;
                 idx = fresh ? cfg.table_base + idx : 0;
-                const TableRec rec = load_record(cfg, idx);
+                const TableRec rec = FAST ? load_record_buffer(cfg, idx) : load_record(cfg, idx);
                 const bool guard = scatter_fate != 0 || (!fresh && ph.iter >= (uint32_t)cfg.max_events);
                 double u_step, u_abs;
                 if (PACKED) {
