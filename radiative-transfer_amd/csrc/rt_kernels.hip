@@ -211,7 +211,10 @@ __global__ __launch_bounds__(kWalkBlock) void walk_kernel(const Cfg cfg0, const 
         cfg.table_base = (int32_t)(it.table * (uint32_t)cfg0.n_wl);
         typename std::conditional<FAST, AccWave, Acc>::type acc;
         acc.clear();
-        unsigned long long wc[RT_NCNT] = {};  // FAST: wave totals, the same value in every lane
+        // FAST: wave totals in scalar registers.  A chunk has at most 16384 photons, so everything that happens
+        // once per photon fits 32 bits; scatterings do not (up to max_events per photon).
+        uint32_t n_photons = 0u, n_escaped = 0u, n_uncounted = 0u, n_guarded = 0u;
+        unsigned long long n_scatter = 0ull;
         Photon ph = {};
         PhiloxSrc src = {};
         src.atm = it.atm;
@@ -234,10 +237,16 @@ __global__ __launch_bounds__(kWalkBlock) void walk_kernel(const Cfg cfg0, const 
             }
         };
 
+        // FAST: the lanes without a photon as a wave-uniform mask, carried from one iteration to the next, so that
+        // every count the loop needs is scalar arithmetic on masks (a ballot of a lane predicate that lives in a
+        // mask register costs a select and a compare per use)
+        unsigned long long dead = ~0ull;
         for (;;) {
             // ---- hand new photon ids to dead lanes (ballot + prefix count) ----
             bool fresh = false;
-            const unsigned long long dead = __builtin_amdgcn_ballot_w64(!alive);
+            if (!FAST) dead = __builtin_amdgcn_ballot_w64(!alive);
+            const uint32_t n_dead = (uint32_t)__popcll(dead);
+            uint32_t n_new = 0u;  // photons started in this iteration (wave-uniform)
             if (dead != 0ull && it.cursor < it.end) {
                 const unsigned int my_off =
                     __builtin_amdgcn_mbcnt_hi((uint32_t)(dead >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dead, 0u));
@@ -250,17 +259,18 @@ __global__ __launch_bounds__(kWalkBlock) void walk_kernel(const Cfg cfg0, const 
                     src.n_emit = 1u;  // the emission block of this iteration is number 0
                     fresh = true;
                 }
-                it.cursor += (unsigned long long)__popcll(dead);
+                const unsigned long long left = it.end - it.cursor;
+                n_new = left < (unsigned long long)n_dead ? (uint32_t)left : n_dead;
+                it.cursor += (unsigned long long)n_dead;
             }
             const bool active = alive || fresh;
-            if (__builtin_amdgcn_ballot_w64(active) == 0ull) break;
+            // FAST: 64 - n_dead lanes scatter, n_new start (a wave of this kernel has 64 lanes)
+            if (FAST ? n_dead - n_new == 64u : __builtin_amdgcn_ballot_w64(active) == 0ull) break;
             if (FAST) {
-                // integer tallies as population counts of lane masks, taken where every lane of the wave arrives
-                wc[RT_CNT_PHOTONS] += (unsigned long long)__popcll(__builtin_amdgcn_ballot_w64(fresh));
-                wc[RT_CNT_SCATTER] += (unsigned long long)__popcll(__builtin_amdgcn_ballot_w64(alive));
+                n_photons += n_new;
+                n_scatter += 64u - n_dead;
             }
             int fate = 0;
-            bool flew = false;
             if (active) {
                 // ---- one Philox call: emission block for fresh lanes, scattering block otherwise ----
                 // (PACKED: the photon's next block serves both, and the flight below as well)
@@ -308,7 +318,6 @@ __global__ __launch_bounds__(kWalkBlock) void walk_kernel(const Cfg cfg0, const 
                 }
                 fate = RT_FATE_GUARD;
                 if (!guard) {
-                    flew = true;
                     int n_used = 0;
                     // FAST: polynomial coefficients from LDS (5 waves per SIMD); the generic kernel is bound by its
                     // other registers (3 waves per SIMD either way) and keeps them in registers
@@ -321,14 +330,26 @@ __global__ __launch_bounds__(kWalkBlock) void walk_kernel(const Cfg cfg0, const 
                 }
             }
             if (FAST) {
-                wc[RT_CNT_FLIGHTS] += (unsigned long long)__popcll(__builtin_amdgcn_ballot_w64(flew));
-                wc[RT_CNT_ESCAPED] += (unsigned long long)__popcll(__builtin_amdgcn_ballot_w64(fate == RT_FATE_ESCAPED));
-                wc[RT_CNT_ESCAPED_UNCOUNTED] +=
-                    (unsigned long long)__popcll(__builtin_amdgcn_ballot_w64(fate == RT_FATE_ESCAPED_UNCOUNTED));
-                wc[RT_CNT_GUARD] += (unsigned long long)__popcll(__builtin_amdgcn_ballot_w64(fate == RT_FATE_GUARD));
+                n_guarded += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(fate == RT_FATE_GUARD));
+                n_escaped += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(fate == RT_FATE_ESCAPED));
+                n_uncounted += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(fate == RT_FATE_ESCAPED_UNCOUNTED));
+                // lanes without a photon at the top of the next iteration: those whose photon ended now (fate is 0
+                // in lanes that were not active) and the dead lanes that got no new one (only when the chunk runs out)
+                unsigned long long idle = 0ull;
+                if (n_new != n_dead) idle = n_new == 0u ? dead : dead & ~__builtin_amdgcn_ballot_w64(fresh);
+                dead = __builtin_amdgcn_ballot_w64(fate != 0) | idle;
             }
         }
         if constexpr (FAST) {
+            unsigned long long wc[RT_NCNT] = {};
+            wc[RT_CNT_PHOTONS] = n_photons;
+            wc[RT_CNT_SCATTER] = n_scatter;
+            wc[RT_CNT_ESCAPED] = n_escaped;
+            wc[RT_CNT_ESCAPED_UNCOUNTED] = n_uncounted;
+            wc[RT_CNT_GUARD] = n_guarded;
+            // one flight per photon started and per scattering, except where the iteration guard ended the photon
+            // after its scattering (fly_path itself never returns RT_FATE_GUARD for an unbounded stream)
+            wc[RT_CNT_FLIGHTS] = n_scatter + n_photons - n_guarded;
             // every photon started in this chunk also ended in it
             wc[RT_CNT_ABSORBED] = wc[RT_CNT_PHOTONS] - wc[RT_CNT_ESCAPED] - wc[RT_CNT_ESCAPED_UNCOUNTED] - wc[RT_CNT_GUARD];
             store_chunk_wave(acc, wc, it, hist, lane, nmu, sw.n_atm, d_chunk_sums, d_counts, d_mu_hist, d_depth);
