@@ -140,7 +140,7 @@ typedef struct rt_params {
     int32_t abs_only;              /* reference global `abs_only`, MC code.py:85, :478-481 */
     int32_t n_mu_bins;             /* escape-cosine histogram bins (0..1), plus one overflow bin for mu >= 1 */
     int32_t n_depth_bins;          /* depth-resolved deposition bins (extension; 0 = off) */
-    int32_t max_events_per_photon; /* iteration guard per photon; <= 0 selects 1<<20 */
+    int32_t max_events_per_photon; /* iteration guard per photon; <= 0 selects 1<<20; capped at 1<<30 */
     int32_t n_slabs;               /* fixed partition of every atmosphere's photon-id range (default 8) */
     int32_t rank;                  /* this context walks slabs s with s % world == rank */
     int32_t world;

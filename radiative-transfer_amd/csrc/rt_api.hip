@@ -136,6 +136,7 @@ rt::Cfg make_cfg(const rt_ctx* ctx, const rt_params* p) {
     c.n_mu_bins = p->n_mu_bins;
     c.n_depth_bins = p->n_depth_bins;
     c.max_events = p->max_events_per_photon > 0 ? p->max_events_per_photon : (1 << 20);
+    if (c.max_events > (1 << 30)) c.max_events = 1 << 30;  // walk blocks stay below the emission blocks (2^31)
     c.alpha = p->alpha;
     c.h = p->h;
     c.geometry = p->geometry;

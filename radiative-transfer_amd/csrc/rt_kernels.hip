@@ -298,7 +298,10 @@ __global__ __launch_bounds__(kWalkBlock) void walk_kernel(const Cfg cfg0, const 
                 const int local = fresh ? idx : 0;
                 idx = fresh ? cfg.table_base + idx : 0;
                 const TableRec rec = FAST ? load_record_buffer(cfg, idx) : load_record(cfg, idx);
-                const bool guard = scatter_fate != 0 || (!fresh && ph.iter >= (uint32_t)cfg.max_events);
+                // the iteration guard: ph.iter flights so far.  In the production kernel a photon that has flown k times
+                // has used 2k blocks at this point, so the block counter serves and ph.iter need not be kept.
+                const bool too_long = MFORM ? src.blk >= 2u * (uint32_t)cfg.max_events : ph.iter >= (uint32_t)cfg.max_events;
+                const bool guard = scatter_fate != 0 || (!fresh && too_long);
                 double u_step, u_abs;
                 if (PACKED) {
                     if (fresh) ++src.blk;
