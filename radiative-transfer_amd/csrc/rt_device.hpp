@@ -513,8 +513,11 @@ __device__ __forceinline__ int scatter(const Cfg& cfg, Photon& ph, Src& src, dou
         } else {
             const double opg2 = LEAN ? 1.0 + ph.g * ph.g : ph.opg2;
             const double omg2 = LEAN ? 1.0 - ph.g * ph.g : ph.omg2;
+            // LEAN: 1/(2g) where it is used (the same div_unit as set_constants, so the same value): most photons of a
+            // thin atmosphere never scatter, and here its sequence interleaves with the division below
+            const double inv2g = LEAN ? div_unit(1.0, 2.0 * ph.g) : ph.inv2g;
             const double q = FAST ? div_unit(omg2, 1.0 + ph.g * s) : omg2 / (1.0 + ph.g * s);
-            mu_prime = ph.inv2g * (opg2 - q * q);
+            mu_prime = inv2g * (opg2 - q * q);
         }
     }
     // RotateIntoLabFrame
