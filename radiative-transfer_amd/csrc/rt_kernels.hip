@@ -241,27 +241,32 @@ __global__ __launch_bounds__(kWalkBlock) void walk_kernel(const Cfg cfg0, const 
         // every count the loop needs is scalar arithmetic on masks (a ballot of a lane predicate that lives in a
         // mask register costs a select and a compare per use)
         unsigned long long dead = ~0ull;
+        // position in the chunk as 32-bit scalars (a chunk has at most 16384 ids; the scalar unit compares 32 bits)
+        const unsigned long long id0 = it.cursor + cfg.id_base;
+        // (a queued chunk can lie wholly beyond the end of a short last slab: it.end < it.cursor, no photons)
+        const uint32_t len = it.end > it.cursor ? (uint32_t)(it.end - it.cursor) : 0u;
+        uint32_t cur = 0u;
         for (;;) {
             // ---- hand new photon ids to dead lanes (ballot + prefix count) ----
             bool fresh = false;
             if (!FAST) dead = __builtin_amdgcn_ballot_w64(!alive);
             const uint32_t n_dead = (uint32_t)__popcll(dead);
             uint32_t n_new = 0u;  // photons started in this iteration (wave-uniform)
-            if (dead != 0ull && it.cursor < it.end) {
+            if (dead != 0ull && cur < len) {
                 const unsigned int my_off =
                     __builtin_amdgcn_mbcnt_hi((uint32_t)(dead >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dead, 0u));
-                const unsigned long long my_id = it.cursor + my_off;
-                if (!alive && my_id < it.end) {
-                    const unsigned long long gid = my_id + cfg.id_base;
+                const uint32_t left = len - cur;
+                n_new = left < n_dead ? left : n_dead;
+                // the first n_new dead lanes, in lane order, take the chunk's next ids
+                if (!alive && my_off < n_new) {
+                    const unsigned long long gid = (id0 + cur) + my_off;  // scalar base + lane offset
                     src.id_lo = (uint32_t)gid;
                     src.id_hi = (uint32_t)(gid >> 32);
                     src.blk = 0u;
                     src.n_emit = 1u;  // the emission block of this iteration is number 0
                     fresh = true;
                 }
-                const unsigned long long left = it.end - it.cursor;
-                n_new = left < (unsigned long long)n_dead ? (uint32_t)left : n_dead;
-                it.cursor += (unsigned long long)n_dead;
+                cur += n_dead;  // may pass len: the chunk is used up then
             }
             const bool active = alive || fresh;
             // FAST: 64 - n_dead lanes scatter, n_new start (a wave of this kernel has 64 lanes)
