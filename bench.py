@@ -213,6 +213,9 @@ def main():
     events_rank_last = events_last / world if world > 1 else events_last  # equal shares by construction
 
     fast = (cfg["boundary"], cfg["scatter"], cfg["order"]) == ("reflect", "hg", "mc")  # the kernel rt_run picks
+    packed = args.rng == "philox32x4"
+    plain = fast and not packed and not cfg["monochromatic"]  # no workload sets rand_mu
+    kernel_name = "walk_kernel<%s, %s, %s>" % tuple("true" if b else "false" for b in (fast, packed, plain))
     if rank == 0:
         value = events / dt
         achieved = events_rank_last * FP64_OPS_PER_EVENT / (kernel_ms * 1e-3) / 1e12
@@ -232,7 +235,7 @@ def main():
             "roofline": {"bound": "valu_fp64", "achieved": achieved, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_VECTOR_PEAK_TFLOPS,
                          "traffic": measured_traffic(cfg["name"], per_gpu),
-                         "kernel": f"walk_kernel<{'true' if fast else 'false'}, {'true' if args.rng == 'philox32x4' else 'false'}>", "kernel_avg_ms": kernel_ms, "kernel_launches": launches,
+                         "kernel": kernel_name, "kernel_avg_ms": kernel_ms, "kernel_launches": launches,
                          "flop_per_event": FP64_OPS_PER_EVENT},
         }
         out.update(cpu)

@@ -86,8 +86,8 @@ struct rt_ctx {
     // result staging for rt_run / rt_replay
     DevBuf<double> d_slab_sums, d_depth, d_sums;
     DevBuf<unsigned long long> d_counts, d_mu_hist;
-    int blocks_per_cu[4] = {0, 0, 0, 0};  // occupancy of walk_kernel<fast, packed> for blocks_lds bytes of LDS
-    size_t blocks_lds[4] = {0, 0, 0, 0};
+    int blocks_per_cu[5] = {0, 0, 0, 0, 0};  // occupancy of walk_kernel<fast, packed, false> ([4]: <true, false, true>) for blocks_lds bytes of LDS
+    size_t blocks_lds[5] = {0, 0, 0, 0, 0};
     // kernel timing
     std::vector<EventPair> events;
     size_t events_used = 0;
@@ -466,10 +466,11 @@ int rt_run_device(rt_ctx* ctx, const rt_params* p, void* d_slab_sums, void* d_co
     const size_t lds = rt::walk_lds_bytes(cfg, fast);
     if (lds > 64 * 1024) return fail(RT_ERR_LIMIT, "histogram bins need %zu bytes of LDS per block (max 65536)", lds);
     const bool packed = p->rng_mode == RT_RNG_PHILOX32X4;
-    const int variant = (fast ? 1 : 0) + (packed ? 2 : 0);
+    const bool plain = fast && !packed && !p->rand_mu && cfg.mono_index < 0;  // the reference's defaults throughout
+    const int variant = plain ? 4 : (fast ? 1 : 0) + (packed ? 2 : 0);
     int& cached = ctx->blocks_per_cu[variant];
     if (cached <= 0 || ctx->blocks_lds[variant] != lds) {
-        cached = rt::walk_max_blocks_per_cu(fast, packed, lds);
+        cached = rt::walk_max_blocks_per_cu(fast, packed, plain, lds);
         ctx->blocks_lds[variant] = lds;
     }
     const int per_cu = cached;
@@ -492,7 +493,7 @@ int rt_run_device(rt_ctx* ctx, const rt_params* p, void* d_slab_sums, void* d_co
     EventPair* ev = nullptr;
     RT_HIP(next_events(ctx, &ev));
     RT_HIP(hipEventRecord(ev->a, stream));
-    RT_HIP(rt::launch_walk(cfg, sw, fast, packed, (int)grid, stream, ctx->d_next.p, ctx->d_chunk_sums.p,
+    RT_HIP(rt::launch_walk(cfg, sw, fast, packed, plain, (int)grid, stream, ctx->d_next.p, ctx->d_chunk_sums.p,
                            (unsigned long long*)d_counts, (unsigned long long*)d_mu_hist, (double*)d_depth));
     RT_HIP(hipEventRecord(ev->b, stream));
     RT_HIP(rt::launch_slab_reduce(sw, ctx->d_chunk_sums.p, (double*)d_slab_sums, stream));

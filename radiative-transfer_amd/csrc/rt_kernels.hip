@@ -188,7 +188,9 @@ __device__ __forceinline__ void store_chunk_wave(const AccWave& acc, const unsig
 //                 boundary, Henyey-Greenstein, no depth bins, abs_only off; integer tallies per wave.
 //   FAST = false  every boundary / scattering law / loop order, depth bins, re-emission, read from cfg.
 // Both give the same photon histories as one fly() + scatter() per photon per iteration (flight()).
-template <bool FAST, bool PACKED>
+//   PLAIN (with FAST) also fixes the reference's defaults rand_mu = 0 and monochromatic = 0 at compile time: the
+//                 selects they cost per emission, and the scalar registers their operands occupy, go away.
+template <bool FAST, bool PACKED, bool PLAIN>
 __global__ __launch_bounds__(kWalkBlock) void walk_kernel(const Cfg cfg0, const Sweep sw,
                                                            unsigned int* __restrict__ d_next,
                                                            double* __restrict__ d_chunk_sums,
@@ -299,7 +301,7 @@ __global__ __launch_bounds__(kWalkBlock) void walk_kernel(const Cfg cfg0, const 
                 }
                 const double prob = __hiloint2double((int)raw.y, (int)raw.x);
                 int idx = (xb - (double)bucket) < prob ? bucket : (int)raw.z;
-                idx = cfg.mono_index >= 0 ? cfg.mono_index : idx;
+                if (!PLAIN) idx = cfg.mono_index >= 0 ? cfg.mono_index : idx;
                 const int local = fresh ? idx : 0;
                 idx = fresh ? cfg.table_base + idx : 0;
                 const TableRec rec = FAST ? load_record_buffer(cfg, idx) : load_record(cfg, idx);
@@ -312,7 +314,7 @@ __global__ __launch_bounds__(kWalkBlock) void walk_kernel(const Cfg cfg0, const 
                     if (fresh) ++src.blk;
                     u_step = u32mid(o.w2);
                     u_abs = u32mid(o.w3);
-                    if (cfg.rand_mu && fresh) {  // the direction draw of a new photon: second uniform of emission block 0
+                    if (!PLAIN && cfg.rand_mu && fresh) {  // the direction draw of a new photon: second uniform of emission block 0
                         const PhiloxOut e = philox4x32_10(src.id_lo, src.id_hi, kEmitBlock, src.atm, src.k0, src.k1);
                         ub = u52(e.w2, e.w3);
                     }
@@ -320,7 +322,7 @@ __global__ __launch_bounds__(kWalkBlock) void walk_kernel(const Cfg cfg0, const 
                     src.pair(u_step, u_abs);
                 }
                 if (fresh) {
-                    set_constants<FAST>(cfg, tau, rec, local, cfg.rand_mu ? ub : 1.0, ph);
+                    set_constants<FAST>(cfg, tau, rec, local, (!PLAIN && cfg.rand_mu) ? ub : 1.0, ph);
                     start_photon(ph, acc);
                     alive = true;
                 }
@@ -577,29 +579,32 @@ size_t walk_lds_bytes(const Cfg& cfg, bool fast) {
            sizeof(uint32_t) * kWavesPerBlock * ((size_t)cfg.n_mu_bins + 1);
 }
 
-int walk_max_blocks_per_cu(bool fast, bool packed, size_t lds_bytes) {
+int walk_max_blocks_per_cu(bool fast, bool packed, bool plain, size_t lds_bytes) {
     int nb = 0;
     hipError_t e =
-        fast ? (packed ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, walk_kernel<true, true>, kWalkBlock, lds_bytes)
-                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, walk_kernel<true, false>, kWalkBlock, lds_bytes))
-             : (packed ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, walk_kernel<false, true>, kWalkBlock, lds_bytes)
-                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, walk_kernel<false, false>, kWalkBlock, lds_bytes));
+        plain ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, walk_kernel<true, false, true>, kWalkBlock, lds_bytes)
+        : fast ? (packed ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, walk_kernel<true, true, false>, kWalkBlock, lds_bytes)
+                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, walk_kernel<true, false, false>, kWalkBlock, lds_bytes))
+               : (packed ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, walk_kernel<false, true, false>, kWalkBlock, lds_bytes)
+                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, walk_kernel<false, false, false>, kWalkBlock, lds_bytes));
     if (e != hipSuccess || nb < 1) nb = 1;
     return nb;
 }
 
-hipError_t launch_walk(const Cfg& cfg, const Sweep& sw, bool fast, bool packed, int grid, hipStream_t stream,
+hipError_t launch_walk(const Cfg& cfg, const Sweep& sw, bool fast, bool packed, bool plain, int grid, hipStream_t stream,
                        unsigned int* d_next, double* d_chunk_sums, unsigned long long* d_counts,
                        unsigned long long* d_mu_hist, double* d_depth) {
     const size_t lds = walk_lds_bytes(cfg, fast);
-    if (fast && !packed)
-        walk_kernel<true, false><<<grid, kWalkBlock, lds, stream>>>(cfg, sw, d_next, d_chunk_sums, d_counts, d_mu_hist, d_depth);
+    if (plain)
+        walk_kernel<true, false, true><<<grid, kWalkBlock, lds, stream>>>(cfg, sw, d_next, d_chunk_sums, d_counts, d_mu_hist, d_depth);
+    else if (fast && !packed)
+        walk_kernel<true, false, false><<<grid, kWalkBlock, lds, stream>>>(cfg, sw, d_next, d_chunk_sums, d_counts, d_mu_hist, d_depth);
     else if (fast)
-        walk_kernel<true, true><<<grid, kWalkBlock, lds, stream>>>(cfg, sw, d_next, d_chunk_sums, d_counts, d_mu_hist, d_depth);
+        walk_kernel<true, true, false><<<grid, kWalkBlock, lds, stream>>>(cfg, sw, d_next, d_chunk_sums, d_counts, d_mu_hist, d_depth);
     else if (!packed)
-        walk_kernel<false, false><<<grid, kWalkBlock, lds, stream>>>(cfg, sw, d_next, d_chunk_sums, d_counts, d_mu_hist, d_depth);
+        walk_kernel<false, false, false><<<grid, kWalkBlock, lds, stream>>>(cfg, sw, d_next, d_chunk_sums, d_counts, d_mu_hist, d_depth);
     else
-        walk_kernel<false, true><<<grid, kWalkBlock, lds, stream>>>(cfg, sw, d_next, d_chunk_sums, d_counts, d_mu_hist, d_depth);
+        walk_kernel<false, true, false><<<grid, kWalkBlock, lds, stream>>>(cfg, sw, d_next, d_chunk_sums, d_counts, d_mu_hist, d_depth);
     return hipGetLastError();
 }
 

@@ -44,9 +44,10 @@ constexpr uint32_t kQueueRows = 1u << kQueueRowsLog2;
 constexpr int kWalkBlock = 256;
 
 size_t walk_lds_bytes(const Cfg& cfg, bool fast);
-int walk_max_blocks_per_cu(bool fast, bool packed, size_t lds_bytes);
+// `plain`: fast, default random stream, rand_mu and monochromatic off (walk_kernel<true, false, true>)
+int walk_max_blocks_per_cu(bool fast, bool packed, bool plain, size_t lds_bytes);
 
-hipError_t launch_walk(const Cfg& cfg, const Sweep& sw, bool fast, bool packed, int grid, hipStream_t stream,
+hipError_t launch_walk(const Cfg& cfg, const Sweep& sw, bool fast, bool packed, bool plain, int grid, hipStream_t stream,
                        unsigned int* d_next, double* d_chunk_sums, unsigned long long* d_counts,
                        unsigned long long* d_mu_hist, double* d_depth);
 
