@@ -253,14 +253,18 @@ __global__ __launch_bounds__(kWalkBlock) void walk_kernel(const Cfg cfg0, const 
             bool fresh = false;
             if (!FAST) dead = __builtin_amdgcn_ballot_w64(!alive);
             const uint32_t n_dead = (uint32_t)__popcll(dead);
-            uint32_t n_new = 0u;  // photons started in this iteration (wave-uniform)
+            uint32_t n_new = 0u;               // photons started in this iteration (wave-uniform)
+            unsigned long long idle = dead;  // FAST: the lanes without a photon that get none in this iteration
             if (dead != 0ull && cur < len) {
                 const unsigned int my_off =
                     __builtin_amdgcn_mbcnt_hi((uint32_t)(dead >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dead, 0u));
                 const uint32_t left = len - cur;
                 n_new = left < n_dead ? left : n_dead;
                 // the first n_new dead lanes, in lane order, take the chunk's next ids
-                if (!alive && my_off < n_new) {
+                const bool take = my_off < n_new;
+                // (the comparison's own lane mask: a ballot of `take` would go through a select and a second compare)
+                if (FAST) idle = dead & ~__builtin_amdgcn_uicmp(my_off, n_new, 36 /* unsigned < */);
+                if (!alive && take) {
                     const unsigned long long gid = (id0 + cur) + my_off;  // scalar base + lane offset
                     src.id_lo = (uint32_t)gid;
                     src.id_hi = (uint32_t)(gid >> 32);
@@ -345,8 +349,6 @@ __global__ __launch_bounds__(kWalkBlock) void walk_kernel(const Cfg cfg0, const 
                 n_uncounted += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(fate == RT_FATE_ESCAPED_UNCOUNTED));
                 // lanes without a photon at the top of the next iteration: those whose photon ended now (fate is 0
                 // in lanes that were not active) and the dead lanes that got no new one (only when the chunk runs out)
-                unsigned long long idle = 0ull;
-                if (n_new != n_dead) idle = n_new == 0u ? dead : dead & ~__builtin_amdgcn_ballot_w64(fresh);
                 dead = __builtin_amdgcn_ballot_w64(fate != 0) | idle;
             }
         }
