@@ -251,10 +251,12 @@ __device__ __forceinline__ void set_constants(const Cfg& cfg, double tau, double
 
 // 16 bytes at base + byte_off as a raw buffer load: the 32-bit offset goes to the instruction as it is, where a
 // global load needs the 64-bit address formed in vector registers first (sign extension, shift, 64-bit add).
+// The caller keeps byte_off + 16 below 2^32 (rt_set_tables_multi limits the tables to 2^26 entries of <= 32 bytes);
+// beyond the descriptor's range the hardware returns zeros instead of faulting.
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint4 gather16(const void* base, uint32_t byte_off) {
     const __amdgpu_buffer_rsrc_t rsrc =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, -1 /* 2^32 - 1 bytes */, 0x00020000);
     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, 0, 0);
     return make_uint4(v.x, v.y, v.z, v.w);
 }
