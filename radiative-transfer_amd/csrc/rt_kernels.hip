@@ -1,6 +1,7 @@
 // rt_kernels.hip -- gfx950 kernels of the photon random walk and their launchers.
 //
-//   walk_kernel<FAST>   persistent scatter kernel (FAST: the production configuration fixed at compile
+//   walk_kernel<FAST, PACKED, PLAIN>
+//                       persistent scatter kernel (FAST: the production configuration fixed at compile
 //                       time; otherwise every flag read at run time).  Every wave pulls work items
 //                       (atmosphere, chunk of photon ids) from a global queue; inside a
 //                       chunk each lane carries one photon in registers and dead lanes are
