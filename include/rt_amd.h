@@ -194,7 +194,8 @@ int rt_device_info(rt_ctx* ctx, char* name, int name_len, int* n_cu, int* wave_s
  * WL, g, Albedo, Scale columns of Grain_data after the join on WL (MC code.py:403-408);
  * pdf[i] is the acceptance probability of wavelength i in AcceptReject (MC code.py:239-268),
  * i.e. P(lambda = wl[i]) is proportional to min(pdf[i], 1).  pdf == NULL means a uniform law.
- * n_wl == 1 gives gray / monochromatic dust. */
+ * n_wl == 1 gives gray / monochromatic dust.
+ * Limits (RT_ERR_LIMIT beyond them): n_wl <= 2^24, n_tables * n_wl <= 2^26. */
 int rt_set_tables(rt_ctx* ctx, int32_t n_wl, const double* wl, const double* g, const double* albedo,
                   const double* scale, const double* pdf);
 
