@@ -563,9 +563,12 @@ __device__ __forceinline__ int flight(const Cfg& cfg, Photon& ph, Src& src, Acc&
 }
 
 // Bookkeeping when a photon's history ends.
-template <class AccT>
+// UNIT_MU0: every photon starts with mu = 1, so its initial momentum p0 = 1 * wh is wh itself and ph.p0 need not
+// be kept.
+template <bool UNIT_MU0 = false, class AccT>
 __device__ __forceinline__ void retire(const Cfg& cfg, const Photon& ph, int fate, AccT& acc, const Hist& hist,
                                        bool shell = false) {
+    const double p0 = UNIT_MU0 ? ph.wh : ph.p0;
     const bool gray = cfg.order == RT_ORDER_GRAY || shell;  // a shell has one escape test: every escape is logged
     acc.count_if(RT_CNT_ESCAPED, fate == RT_FATE_ESCAPED);
     acc.count_if(RT_CNT_ESCAPED_UNCOUNTED, fate == RT_FATE_ESCAPED_UNCOUNTED);
@@ -574,10 +577,10 @@ __device__ __forceinline__ void retire(const Cfg& cfg, const Photon& ph, int fat
     acc.count_if(RT_CNT_GUARD, fate == RT_FATE_GUARD);
     acc.add(RT_SUM_ESCAPED, ph.e1);
     acc.add(RT_SUM_BOUNDARY, ph.b);
-    const double t = shell ? ph.dep : ph.p0 - ph.e1 + ph.b;
+    const double t = shell ? ph.dep : p0 - ph.e1 + ph.b;
     acc.add(RT_SUM_TRANSFER_SQ, t * t);
-    acc.add(RT_SUM_TRANSFER_P0, t * ph.p0);
-    acc.add(RT_SUM_P0_SQ, ph.p0 * ph.p0);
+    acc.add(RT_SUM_TRANSFER_P0, t * p0);
+    acc.add(RT_SUM_P0_SQ, p0 * p0);
     if (hist.mu && ((fate == RT_FATE_ESCAPED && gray) || fate == RT_FATE_ESCAPED_UNCOUNTED)) {
         int k = (int)floor((double)cfg.n_mu_bins * ph.mu);
         k = k < 0 ? 0 : k;

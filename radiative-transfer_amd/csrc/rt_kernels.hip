@@ -331,8 +331,9 @@ __global__ __launch_bounds__(kWalkBlock) void walk_kernel(const Cfg cfg0, const 
                     start_photon(ph, acc);
                     alive = true;
                 }
-                fate = RT_FATE_GUARD;
-                if (!guard) {
+                if (guard) {
+                    fate = RT_FATE_GUARD;
+                } else {
                     int n_used = 0;
                     // FAST: polynomial coefficients from LDS (5 waves per SIMD); the generic kernel is bound by its
                     // other registers (3 waves per SIMD either way) and keeps them in registers
@@ -340,7 +341,7 @@ __global__ __launch_bounds__(kWalkBlock) void walk_kernel(const Cfg cfg0, const 
                     fate = fly_path<FAST>(cfg, ph, path, u_abs, 2, false, acc, hist, reemit, n_used);
                 }
                 if (fate != 0) {
-                    retire(cfg, ph, fate, acc, hist, !FAST && cfg.geometry == RT_GEOM_SHELL);
+                    retire<PLAIN>(cfg, ph, fate, acc, hist, !FAST && cfg.geometry == RT_GEOM_SHELL);
                     alive = false;
                 }
             }
