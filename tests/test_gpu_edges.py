@@ -108,3 +108,34 @@ def test_all_flag_combinations_smoke(rt, engine, c_oracle):
                     res = engine.run(rt.make_params(tau, 1500, **kw))
                     ref = c_oracle.run(c_oracle.make_params(tau, 1500, **kw), *t)
                     same(res, ref)
+
+
+def test_slabs_beyond_the_last_photon(rt, engine, c_oracle):
+    """Fewer photons than the slab partition has room for: the chunks of the last slabs start beyond the last
+    photon id (their end lies below their start) and must contribute nothing."""
+    t = table()
+    engine.set_tables(*t)
+    tau = np.array([1.0, 3.0, 0.2])
+    for n in ([9, 1, 2], [17, 5, 8]):       # n_slabs = 8: slab length 2 / 1 / 1, slabs 5..7 of the first are empty
+        n = np.array(n, dtype=np.uint64)
+        res = engine.run(rt.make_params(tau, n))
+        ref = c_oracle.run(c_oracle.make_params(tau, n), *t)
+        same(res, ref)
+        assert list(res.counts[:, rt._abi.CNT_PHOTONS]) == list(n)
+
+
+def test_results_do_not_depend_on_the_work_order(rt, engine):
+    """A launch with many chunks per resident wave (here 52 000 over 5120 waves) hands them out in interleaved
+    rows, a short one heaviest first.  A chunk's tallies depend on its photon ids only, so the first 100 of 500
+    atmospheres in one launch give, bit for bit, what a launch of those 100 alone gives (same atmosphere
+    indices, hence the same Philox counters)."""
+    t = table()
+    engine.set_tables(*t)
+    tau = np.logspace(-3, 2, 500)
+    n = 100000
+    whole = engine.run(rt.make_params(tau, n, n_mu_bins=10))
+    assert np.all(whole.counts[:, rt._abi.CNT_PHOTONS] == n)
+    first = engine.run(rt.make_params(tau[:100], n, n_mu_bins=10))
+    assert np.array_equal(first.counts, whole.counts[:100])
+    assert np.array_equal(first.mu_hist, whole.mu_hist[:100])
+    assert np.array_equal(first.sums, whole.sums[:100])
