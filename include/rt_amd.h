@@ -138,8 +138,10 @@ typedef struct rt_params {
     int32_t loop_order;            /* RT_ORDER_* */
     int32_t rand_mu;               /* reference global `rand_mu`,  MC code.py:84, :384-385 */
     int32_t abs_only;              /* reference global `abs_only`, MC code.py:85, :478-481 */
-    int32_t n_mu_bins;             /* escape-cosine histogram bins (0..1), plus one overflow bin for mu >= 1 */
-    int32_t n_depth_bins;          /* depth-resolved deposition bins (extension; 0 = off) */
+    int32_t n_mu_bins;             /* escape-cosine histogram bins (0..1), plus one overflow bin for mu >= 1; <= 4096 */
+    int32_t n_depth_bins;          /* depth-resolved deposition bins (extension; 0 = off); <= 1024, and together
+                                      16 * (n_mu_bins + 1) + 64 * n_depth_bins <= 63360 (both histograms are kept per wave
+                                      in 64 KiB of LDS); RT_ERR_LIMIT beyond that, before anything is enqueued */
     int32_t max_events_per_photon; /* iteration guard per photon; <= 0 selects 1<<20; capped at 1<<30 */
     int32_t n_slabs;               /* fixed partition of every atmosphere's photon-id range (default 8) */
     int32_t rank;                  /* this context walks slabs s with s % world == rank */

@@ -250,8 +250,10 @@ def run_photons(tau_atm, lam, g, albedo, scale, mu0, *, boundary="reflect", scat
             iso_now = first_scatter or iso_forever
         if gray and scatter == "hg" and np.all(g == 0):
             iso_now = True
+        if scatter == "draine" and np.all(g == 0) and alpha == 0:   # Numpy_random_walk.py:388-391
+            iso_now = True
         first_scatter = False
-        if scatter == "draine":
+        if scatter == "draine" and not iso_now:
             if not gray or not isinstance(stream, GlobalStream):
                 raise ValueError("the Draine phase function is restated for the gray order with a global generator only")
             phi = 2 * np.pi * stream.draw(ids)

@@ -349,6 +349,7 @@ static void walk_one(const rt_params* p, double tau, const tables_t* t, stream_t
         int iso = 0, direct = 0;
         if (p->scatter == RT_SCATTER_ISO) iso = gray ? 1 : (iter == 1);
         if (gray && p->scatter == RT_SCATTER_HG && c.g == 0) iso = 1;
+        if (p->scatter == RT_SCATTER_DRAINE && c.g == 0 && p->alpha == 0) iso = 1; /* Numpy_random_walk.py:388-391 */
         double u_phi, u_s, mu_prime = 0;
         if (!draw(s, &u_phi)) { fate = RT_FATE_GUARD; break; }
         if ((p->scatter == RT_SCATTER_DRAINE || p->scatter == RT_SCATTER_DRAINE_EXACT) && !iso) {

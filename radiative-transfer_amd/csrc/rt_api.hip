@@ -108,6 +108,13 @@ int check_common(const rt_params* p) {
     if (p->loop_order < 0 || p->loop_order > 1) return fail(RT_ERR_INVALID, "loop_order=%d", p->loop_order);
     if (p->n_mu_bins < 0 || p->n_mu_bins > 4096) return fail(RT_ERR_LIMIT, "n_mu_bins must be in [0, 4096]");
     if (p->n_depth_bins < 0 || p->n_depth_bins > 1024) return fail(RT_ERR_LIMIT, "n_depth_bins must be in [0, 1024]");
+    {   // both histograms are private to each of a workgroup's waves and live in LDS next to the math tables
+        const size_t lds = rt::walk_lds_bytes(p->n_mu_bins, p->n_depth_bins);
+        if (lds > rt::kWalkLdsLimit)
+            return fail(RT_ERR_LIMIT, "n_mu_bins=%d with n_depth_bins=%d needs %zu bytes of LDS per workgroup (limit %zu: "
+                        "16*(n_mu_bins+1) + 64*n_depth_bins <= %zu)", p->n_mu_bins, p->n_depth_bins, lds, rt::kWalkLdsLimit,
+                        rt::kWalkLdsLimit - rt::walk_lds_bytes(-1, 0));
+    }
     if (p->scatter == RT_SCATTER_DRAINE && p->loop_order != RT_ORDER_GRAY)
         return fail(RT_ERR_INVALID,
                     "scatter='draine' is only available with the gray loop order (it is disabled in the "
@@ -334,7 +341,8 @@ int rt_set_tables_multi(rt_ctx* ctx, int32_t n_tables, int32_t n_wl, const doubl
     }
     RT_HIP(ctx->d_rec.reserve(total_n));
     RT_HIP(ctx->d_alias.reserve(total_n));
-    RT_HIP(hipStreamSynchronize(ctx->stream));
+    // a sweep enqueued on a caller's stream (rt_run_device) may still be reading the old tables
+    RT_HIP(hipDeviceSynchronize());
     RT_HIP(hipMemcpy(ctx->d_rec.p, rec.data(), sizeof(rt::TableRec) * total_n, hipMemcpyHostToDevice));
     RT_HIP(hipMemcpy(ctx->d_alias.p, alias.data(), sizeof(rt::AliasEntry) * total_n, hipMemcpyHostToDevice));
     RT_HIP(ctx->d_lam.reserve(n));
@@ -463,8 +471,7 @@ int rt_run_device(rt_ctx* ctx, const rt_params* p, void* d_slab_sums, void* d_co
     const bool fast = p->loop_order == RT_ORDER_MC && p->boundary == RT_BOUNDARY_REFLECT &&
                       p->scatter == RT_SCATTER_HG && p->n_depth_bins == 0 && !p->abs_only &&
                       p->geometry == RT_GEOM_SLAB;
-    const size_t lds = rt::walk_lds_bytes(cfg, fast);
-    if (lds > 64 * 1024) return fail(RT_ERR_LIMIT, "histogram bins need %zu bytes of LDS per block (max 65536)", lds);
+    const size_t lds = rt::walk_lds_bytes(cfg.n_mu_bins, fast ? 0 : cfg.n_depth_bins);  // within the limit: check_common
     const bool packed = p->rng_mode == RT_RNG_PHILOX32X4;
     const bool plain = fast && !packed && !p->rand_mu && cfg.mono_index < 0;  // the reference's defaults throughout
     const int variant = plain ? 4 : (fast ? 1 : 0) + (packed ? 2 : 0);

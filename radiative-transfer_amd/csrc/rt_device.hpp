@@ -475,6 +475,8 @@ __device__ __forceinline__ int scatter(const Cfg& cfg, Photon& ph, Src& src, dou
     if (!FAST) {
         if (law == RT_SCATTER_ISO) iso = gray ? true : (ph.iter == 1u);
         if (gray && law == RT_SCATTER_HG && ph.g == 0.0) iso = true;
+        // the gray script's Draine branch falls back to IsoScatter for g == 0 and alpha == 0 (Numpy_random_walk.py:388-391)
+        if (law == RT_SCATTER_DRAINE && ph.g == 0.0 && cfg.alpha == 0.0) iso = true;
     }
     double mu_prime;
     bool direct = false;

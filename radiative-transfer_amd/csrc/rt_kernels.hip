@@ -577,10 +577,9 @@ hipError_t launch_selftest_math(const LogTableEntry* d_table, long long n, const
     return hipGetLastError();
 }
 
-size_t walk_lds_bytes(const Cfg& cfg, bool fast) {
-    const size_t nd = fast ? 0 : (size_t)cfg.n_depth_bins;
-    return kMathLdsBytes + sizeof(double) * kWavesPerBlock * 2 * nd +
-           sizeof(uint32_t) * kWavesPerBlock * ((size_t)cfg.n_mu_bins + 1);
+size_t walk_lds_bytes(int n_mu_bins, int n_depth_bins) {
+    return kMathLdsBytes + sizeof(double) * kWavesPerBlock * 2 * (size_t)n_depth_bins +
+           sizeof(uint32_t) * kWavesPerBlock * (size_t)(n_mu_bins + 1);
 }
 
 int walk_max_blocks_per_cu(bool fast, bool packed, bool plain, size_t lds_bytes) {
@@ -598,7 +597,7 @@ int walk_max_blocks_per_cu(bool fast, bool packed, bool plain, size_t lds_bytes)
 hipError_t launch_walk(const Cfg& cfg, const Sweep& sw, bool fast, bool packed, bool plain, int grid, hipStream_t stream,
                        unsigned int* d_next, double* d_chunk_sums, unsigned long long* d_counts,
                        unsigned long long* d_mu_hist, double* d_depth) {
-    const size_t lds = walk_lds_bytes(cfg, fast);
+    const size_t lds = walk_lds_bytes(cfg.n_mu_bins, fast ? 0 : cfg.n_depth_bins);
     if (plain)
         walk_kernel<true, false, true><<<grid, kWalkBlock, lds, stream>>>(cfg, sw, d_next, d_chunk_sums, d_counts, d_mu_hist, d_depth);
     else if (fast && !packed)
@@ -625,7 +624,7 @@ hipError_t launch_replay(const Cfg& cfg, double tau, long long n, int max_draws,
                          unsigned long long* d_mu_hist, double* d_depth, rt_photon_trace* d_trace,
                          hipStream_t stream) {
     if (n <= 0) return hipSuccess;
-    const size_t lds = walk_lds_bytes(cfg, false);
+    const size_t lds = walk_lds_bytes(cfg.n_mu_bins, cfg.n_depth_bins);
     const unsigned int grid = (unsigned int)((n + kWalkBlock - 1) / kWalkBlock);
     replay_kernel<<<grid, kWalkBlock, lds, stream>>>(cfg, tau, n, max_draws, d_xi, d_lam, d_g, d_albedo, d_scale, d_mu0,
                                                      d_sums, d_counts, d_mu_hist, d_depth, d_trace);

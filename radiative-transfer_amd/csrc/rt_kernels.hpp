@@ -43,7 +43,10 @@ constexpr uint32_t kQueueRows = 1u << kQueueRowsLog2;
 
 constexpr int kWalkBlock = 256;
 
-size_t walk_lds_bytes(const Cfg& cfg, bool fast);
+// LDS per workgroup of the walk / replay kernels: math tables + per-wave histograms of n_mu_bins + 1 and 2 * n_depth_bins
+// entries.  The limit leaves room for several workgroups per compute unit.
+size_t walk_lds_bytes(int n_mu_bins, int n_depth_bins);
+constexpr size_t kWalkLdsLimit = 64 * 1024;
 // `plain`: fast, default random stream, rand_mu and monochromatic off (walk_kernel<true, false, true>)
 int walk_max_blocks_per_cu(bool fast, bool packed, bool plain, size_t lds_bytes);
 

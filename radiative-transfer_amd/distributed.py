@@ -1,11 +1,16 @@
-"""One process per GPU: photon-id slabs dealt round-robin to ranks, one all-reduce of the tallies.
+"""One process per GPU: photon-id slabs dealt round-robin to ranks, ONE all-reduce of the tallies.
 
 Photons and atmospheres are independent, so the walk shards without any exchange while it runs.
 Every atmosphere's photon-id range is cut into ``n_slabs`` fixed slabs (the cut does not depend on
-the number of ranks); rank r walks the slabs s with s % world == r.  Each slab's partial sums are
-produced by exactly one rank and are zero elsewhere, so a sum all-reduce (RCCL on GPUs, gloo in the
-CPU tests) returns them unchanged -- adding zeros is exact -- and the final sum over the slab axis is
-done in slab order on every rank.  The result is bit-for-bit the same for 1, 2, 4 or 8 ranks.
+the number of ranks); rank r walks the slabs s with s % world == r.  The sweep writes its slab
+partial sums (fp64), integer tallies and escape-cosine histogram into ONE device buffer
+(``TallyBuffer``), which is all-reduced once as 64-bit integers (RCCL on GPUs, gloo in the CPU
+tests): the integer tallies add as integers, and every slab entry is non-zero on exactly one rank
+and all-zero bits elsewhere, so adding the bit patterns returns that rank's double unchanged.  The
+final sum over the slab axis is done in slab order on every rank.  The result is bit-for-bit the
+same for 1, 2, 4 or 8 ranks.  Depth-resolved deposition (``n_depth_bins > 0``) is accumulated with
+floating-point atomics on every rank, so it needs a floating-point sum of its own: a second, fp64
+all-reduce that only runs when depth bins are requested.
 torch is used for device buffers and the collective only.
 """
 import numpy as np
@@ -14,13 +19,54 @@ from . import _abi as abi
 from .engine import SweepResult, make_params
 
 
-def all_reduce_tallies(tensors, group=None):
-    """In-place sum all-reduce of the tally tensors (no-op for a single process)."""
+class TallyBuffer:
+    """Slab sums, counts and escape-cosine histogram of one sweep in one int64 tensor.
+
+    Layout (64-bit words): [n_atm][n_slabs][NSUM] doubles | [n_atm][NCNT] u64 | [n_atm][n_mu_bins+1] u64.
+    ``words`` is what the collective sees; ``slab``, ``counts`` and ``hist`` are views of it."""
+
+    def __init__(self, torch, n_atm, n_slabs, n_mu_bins, device):
+        self.shape = (n_atm, n_slabs, n_mu_bins)
+        n_slab, n_cnt, n_hist = n_atm * n_slabs * abi.NSUM, n_atm * abi.NCNT, n_atm * (n_mu_bins + 1)
+        self.words = torch.zeros(n_slab + n_cnt + n_hist, dtype=torch.int64, device=device)
+        self.slab = self.words[:n_slab].view(torch.float64)
+        self.counts = self.words[n_slab:n_slab + n_cnt]
+        self.hist = self.words[n_slab + n_cnt:]
+
+    def pointers(self):
+        """Device addresses of the three parts, as rt_run_device wants them."""
+        return self.slab.data_ptr(), self.counts.data_ptr(), self.hist.data_ptr()
+
+    def all_reduce(self, group=None):
+        """The run's only collective (no-op for a single process).  With the gloo backend (CPU rehearsal of
+        N > 1) the words are staged through host memory."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+            return
+        if self.words.is_cuda and dist.get_backend(group) == "gloo":
+            host = self.words.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+            self.words.copy_(host)
+        else:
+            dist.all_reduce(self.words, op=dist.ReduceOp.SUM, group=group)
+
+    def result(self, depth=None, n_depth_bins=0):
+        n_atm, n_slabs, n_mu_bins = self.shape
+        return result_from_arrays(self.slab.cpu().numpy(), self.counts.cpu().numpy(), self.hist.cpu().numpy(),
+                                  None if depth is None else depth.cpu().numpy(), n_atm, n_mu_bins, n_depth_bins, n_slabs)
+
+
+def all_reduce_depth(depth, group=None):
+    """Floating-point sum of the depth-resolved deposition over the ranks (only with n_depth_bins > 0)."""
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        for t in tensors:
-            if t is not None:
-                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    if depth is None or not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+        return
+    if depth.is_cuda and dist.get_backend(group) == "gloo":
+        host = depth.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        depth.copy_(host)
+    else:
+        dist.all_reduce(depth, op=dist.ReduceOp.SUM, group=group)
 
 
 def result_from_arrays(slab_sums, counts, mu_hist, depth, n_atm, n_mu_bins, n_depth_bins, n_slabs):
@@ -29,7 +75,7 @@ def result_from_arrays(slab_sums, counts, mu_hist, depth, n_atm, n_mu_bins, n_de
     res.counts[...] = np.asarray(counts).reshape(n_atm, abi.NCNT).astype(np.uint64)
     res.mu_hist[...] = np.asarray(mu_hist).reshape(n_atm, n_mu_bins + 1).astype(np.uint64)
     if n_depth_bins:
-        d = np.asarray(depth, dtype=np.float64).reshape(2, n_atm, n_depth_bins)
+        d = np.asarray(depth, dtype=np.float64).reshape(-1)[:2 * n_atm * n_depth_bins].reshape(2, n_atm, n_depth_bins)
         res.depth_momentum[...] = d[0]
         res.depth_energy[...] = d[1]
     res.finalize_from_slabs()
@@ -54,26 +100,23 @@ class DistributedSweep:
         key = (n_atm, n_slabs, n_mu_bins, n_depth_bins)
         if key not in self._bufs:
             t = self.torch
-            self._bufs[key] = (t.zeros(n_atm * n_slabs * abi.NSUM, dtype=t.float64, device=self.device),
-                               t.zeros(n_atm * abi.NCNT, dtype=t.int64, device=self.device),
-                               t.zeros(n_atm * (n_mu_bins + 1), dtype=t.int64, device=self.device),
-                               t.zeros(max(2 * n_atm * n_depth_bins, 1), dtype=t.float64, device=self.device))
+            self._bufs[key] = (TallyBuffer(t, n_atm, n_slabs, n_mu_bins, self.device),
+                               t.zeros(2 * n_atm * n_depth_bins, dtype=t.float64, device=self.device) if n_depth_bins else None)
         return self._bufs[key]
 
     def enqueue(self, tau, n_photons, n_slabs=8, **kw):
-        """Launch the sweep for this rank's slabs and the all-reduce; returns the device tensors."""
+        """Launch the sweep for this rank's slabs and the all-reduce; returns the device buffers."""
         if n_slabs % self.world:
             raise ValueError(f"n_slabs ({n_slabs}) must be a multiple of the number of ranks ({self.world})")
         prm = make_params(tau, n_photons, n_slabs=n_slabs, rank=self.rank, world=self.world, **kw)
-        slab, counts, hist, depth = self._buffers(prm.n_atm, n_slabs, prm.n_mu_bins, prm.n_depth_bins)
+        buf, depth = self._buffers(prm.n_atm, n_slabs, prm.n_mu_bins, prm.n_depth_bins)
         stream = self.torch.cuda.current_stream(self.device).cuda_stream
-        self.engine.run_device(prm, slab.data_ptr(), counts.data_ptr(), hist.data_ptr(),
-                               depth.data_ptr() if prm.n_depth_bins else None, stream)
-        all_reduce_tallies([slab, counts, hist, depth if prm.n_depth_bins else None], self.group)
-        return prm, (slab, counts, hist, depth)
+        self.engine.run_device(prm, *buf.pointers(), depth.data_ptr() if depth is not None else None, stream)
+        buf.all_reduce(self.group)
+        all_reduce_depth(depth, self.group)
+        return prm, (buf, depth)
 
     def run(self, tau, n_photons, n_slabs=8, **kw):
-        prm, (slab, counts, hist, depth) = self.enqueue(tau, n_photons, n_slabs, **kw)
+        prm, (buf, depth) = self.enqueue(tau, n_photons, n_slabs, **kw)
         self.torch.cuda.synchronize(self.device)
-        return result_from_arrays(slab.cpu().numpy(), counts.cpu().numpy(), hist.cpu().numpy(), depth.cpu().numpy(),
-                                  prm.n_atm, prm.n_mu_bins, prm.n_depth_bins, n_slabs)
+        return buf.result(depth, prm.n_depth_bins)

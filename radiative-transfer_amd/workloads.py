@@ -57,7 +57,7 @@ def five_species_1e9(wl_list=None, grain_mix=(0.2, 0.2, 0.2, 0.2, 0.2)):
                    describe="Sil/Gra/SiC/SUV/PAH equal mix, Planck(3e4 K) emission, reflect + hg")
 
 
-def species_radius_batch(wl_list=None, radii_pc=(5, 10, 20, 50, 100), total_histories=10 ** 10):
+def species_radius_batch(wl_list=None, radii_pc=(5, 10, 15, 20, 500), total_histories=10 ** 10):
     """Config 5: 5 shell radii x {Sil, Gra, SiC, mix} x 100 optical depths as ONE sweep of 2000 atmospheres over
     four grain tables (set_tables with 2-D columns + table_of_atm); 1e10 photon histories split evenly.  The
     radius only enters the conversion tau -> column density afterwards (tau_to_radius), so each radius repeats

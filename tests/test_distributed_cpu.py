@@ -1,6 +1,7 @@
 """The N > 1 path on CPU: two gloo ranks each own half of the slabs (here filled by the CPU oracle, which
-honours rank / world exactly like the kernel), all-reduce the tallies with the product's own combine code,
-and must reproduce the single-rank result bit for bit."""
+honours rank / world exactly like the kernel), all-reduce the tallies with the product's own combine code --
+one int64 buffer holding the doubles' bit patterns, the counts and the histogram, one collective -- and must
+reproduce the single-rank result bit for bit."""
 import importlib
 import os
 import socket
@@ -42,12 +43,20 @@ def _worker(rank, world, port, out_path):
     D = importlib.import_module("radiative-transfer_amd.distributed")
     A = importlib.import_module("radiative-transfer_amd._abi")
     t = c_oracle.run(c_oracle.make_params(TAU, N_PHOTONS, rank=rank, world=world, **KW), *_table())
-    slab = torch.from_numpy(t.slab_sums.reshape(-1).copy())
-    counts = torch.from_numpy(t.counts.astype(np.int64).reshape(-1).copy())
-    hist = torch.from_numpy(t.mu_hist.astype(np.int64).reshape(-1).copy())
+    # the product's own packed buffer (one int64 tensor, one collective), here on the CPU
+    buf = D.TallyBuffer(torch, len(TAU), 8, 10, "cpu")
+    buf.slab.copy_(torch.from_numpy(t.slab_sums.reshape(-1).copy()))
+    buf.counts.copy_(torch.from_numpy(t.counts.astype(np.int64).reshape(-1).copy()))
+    buf.hist.copy_(torch.from_numpy(t.mu_hist.astype(np.int64).reshape(-1).copy()))
     depth = torch.from_numpy(np.stack([t.depth_momentum, t.depth_energy]).reshape(-1).copy())
-    D.all_reduce_tallies([slab, counts, hist, depth])
-    res = D.result_from_arrays(slab.numpy(), counts.numpy(), hist.numpy(), depth.numpy(), len(TAU), 10, 4, 8)
+    calls = []
+    real = dist.all_reduce
+    dist.all_reduce = lambda *a, **k: (calls.append(a[0].dtype), real(*a, **k))[1]
+    buf.all_reduce()
+    assert calls == [torch.int64]            # ONE collective for sums, counts and histogram
+    D.all_reduce_depth(depth)
+    dist.all_reduce = real
+    res = buf.result(depth, 4)
     np.savez(out_path % rank, sums=res.sums, slab=res.slab_sums, counts=res.counts, hist=res.mu_hist,
              dm=res.depth_momentum)
     dist.destroy_process_group()

@@ -63,7 +63,8 @@ def test_iteration_guard(rt, engine, c_oracle):
     ref = c_oracle.run(c_oracle.make_params(np.array([1e4]), 2000, **kw), [0.5], [0.3], [1.0], [1.0])
     same(res, ref)
     assert res.counts[0, A.CNT_GUARD] > 1900
-    assert res.counts[0, A.CNT_FLIGHTS] == res.counts[0, A.CNT_GUARD] * 50 + (res.counts[0, A.CNT_FLIGHTS] - res.counts[0, A.CNT_GUARD] * 50)
+    # a guarded photon flew exactly 50 times, every other one fewer
+    assert res.counts[0, A.CNT_GUARD] * 50 <= res.counts[0, A.CNT_FLIGHTS] < 2000 * 50
     # NaN optical constants (a wavelength without table entry in the reference's left join): never escapes,
     # never absorbed -> the reference loops forever, here the guard retires the photon
     engine.set_tables([0.5], [np.nan], [np.nan], [np.nan])
@@ -139,3 +140,15 @@ def test_results_do_not_depend_on_the_work_order(rt, engine):
     assert np.array_equal(first.counts, whole.counts[:100])
     assert np.array_equal(first.mu_hist, whole.mu_hist[:100])
     assert np.array_equal(first.sums, whole.sums[:100])
+
+
+def test_histogram_limit_is_reported_before_any_device_work(rt, engine):
+    """Both histograms live in LDS per wave; a combination that does not fit is refused during validation, and the
+    caller's result arrays are not touched."""
+    engine.set_tables([0.5], [0.3], [0.5], [1.0])
+    with pytest.raises(rt.RtError, match="LDS"):
+        engine.run(rt.make_params(np.array([1.0]), 100, n_mu_bins=4096, monochromatic=0.5))
+    with pytest.raises(rt.RtError, match="LDS"):
+        engine.run(rt.make_params(np.array([1.0]), 100, n_mu_bins=2000, n_depth_bins=512, monochromatic=0.5))
+    res = engine.run(rt.make_params(np.array([1.0]), 100, n_mu_bins=3900, monochromatic=0.5))   # just inside
+    assert res.counts[0, rt._abi.CNT_PHOTONS] == 100

@@ -1,0 +1,108 @@
+"""More than one rank on real hardware.  A one-GPU box can still run the whole N > 1 path -- rank processes, slab
+ownership, the packed tally buffer, the collective, bench.py's launcher -- with the ranks sharing the GPU and the
+gloo backend carrying the collective; with two or more GPUs the same test also runs over RCCL.  Results must equal
+the single-rank result bit for bit."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+WORKER = r"""
+import importlib, os, sys
+import numpy as np
+import torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+backend, out = sys.argv[2], sys.argv[3]
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dev = rank % torch.cuda.device_count()
+torch.cuda.set_device(dev)
+if backend == "nccl":
+    dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+else:
+    dist.init_process_group("gloo")
+rt = importlib.import_module("radiative-transfer_amd")
+D = importlib.import_module("radiative-transfer_amd.distributed")
+n = 64
+wl = np.round(np.linspace(0.1, 1.0, n), 4)
+eng = rt.Engine(dev)
+eng.set_tables(wl, np.linspace(0.3, 0.8, n), np.linspace(0.4, 0.9, n), np.linspace(2.0, 0.5, n), np.linspace(1.0, 0.1, n) / n)
+res = D.DistributedSweep(eng).run(np.array([0.05, 0.7, 9.0]), 300007, n_mu_bins=10, n_depth_bins=4)
+np.savez(out % rank, sums=res.sums, slab=res.slab_sums, counts=res.counts, hist=res.mu_hist, dm=res.depth_momentum)
+dist.destroy_process_group()
+eng.close()
+"""
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run_ranks(world, backend, tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    out = str(tmp_path / f"{backend}_rank%d.npz")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE=str(world),
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, backend, out], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)))
+             for r in range(world)]
+    codes = [p.wait(timeout=300) for p in procs]
+    assert codes == [0] * world
+    return [np.load(out % r) for r in range(world)]
+
+
+def _single(rt, engine):
+    n = 64
+    wl = np.round(np.linspace(0.1, 1.0, n), 4)
+    engine.set_tables(wl, np.linspace(0.3, 0.8, n), np.linspace(0.4, 0.9, n), np.linspace(2.0, 0.5, n), np.linspace(1.0, 0.1, n) / n)
+    return engine.run(rt.make_params(np.array([0.05, 0.7, 9.0]), 300007, n_mu_bins=10, n_depth_bins=4))
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_ranks_sharing_one_gpu_match_one_rank(rt, engine, tmp_path, world):
+    one = _single(rt, engine)
+    for r in _run_ranks(world, "gloo", tmp_path):
+        assert np.array_equal(r["slab"], one.slab_sums) and np.array_equal(r["sums"], one.sums)
+        assert np.array_equal(r["counts"], one.counts) and np.array_equal(r["hist"], one.mu_hist)
+        np.testing.assert_allclose(r["dm"], one.depth_momentum, rtol=1e-12)
+
+
+def test_two_gpus_over_rccl_match_one_rank(rt, engine, tmp_path):
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    one = _single(rt, engine)
+    for r in _run_ranks(2, "nccl", tmp_path):
+        assert np.array_equal(r["slab"], one.slab_sums) and np.array_equal(r["sums"], one.sums)
+        assert np.array_equal(r["counts"], one.counts) and np.array_equal(r["hist"], one.mu_hist)
+
+
+def _bench(*args):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu", "--workload", "sil_single_1e6",
+                        "--steps", "2", "--warmup", "1", *args], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    return json.loads(p.stdout.strip().splitlines()[-1])
+
+
+def test_bench_launches_its_own_ranks_and_is_strong_scaled():
+    """`python bench.py --gpus 2` as the driver invokes it (no launcher, WORLD_SIZE unset): two rank processes, the
+    same job as one rank (strong scaling), one collective per step, identical event count."""
+    one = _bench("--gpus", "1")
+    two = _bench("--gpus", "2", "--backend", "gloo")
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["scaling"] == "strong"
+    assert "1 all-reduce per step" in two["config"]["parallelism"]
+    for k in ("photons_per_atmosphere_global", "photon_histories_per_step", "flights_per_step", "events_per_step"):
+        assert one["config"][k] == two["config"][k]
+    assert two["value"] > 0 and two["roofline"]["kernel_launches"] == 2
