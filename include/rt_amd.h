@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 3
+#define RT_ABI_VERSION 4
 
 typedef enum rt_status {
     RT_OK = 0,
@@ -225,6 +225,21 @@ int rt_run(rt_ctx* ctx, const rt_params* p, rt_tallies* out);
  * sweeps of one context in flight on different streams race.  Use one context per concurrent stream. */
 int rt_run_device(rt_ctx* ctx, const rt_params* p, void* d_slab_sums, void* d_counts, void* d_mu_hist,
                   void* d_depth, void* stream);
+
+/* The same sweep for callers that cannot allocate: code under HIP graph capture, tight serving loops, harnesses
+ * that forbid hipMalloc.  No counterpart in the reference.  Same arguments and results as rt_run_device, bit for
+ * bit, but the work memory (work queue, plan, chunk partial sums) is a static device array of 32 MiB that the
+ * library holds on every GPU it runs on from load to process exit, and the call itself allocates nothing on the
+ * device or the host and frees nothing; its kernel is not timed (rt_kernel_time does not see it).
+ * Limits (RT_ERR_LIMIT beyond them, before anything is enqueued): n_atm <= 4096, and the work memory within the
+ * array: 52 * n_atm bytes of plan, up to 8 MiB of tally copies (8 * n_atm * (RT_NCNT + n_mu_bins + 1) bytes each, as
+ * many as fit, at most 64) and 80 bytes per chunk of this rank's slabs (a chunk is 8192 photon ids for slabs of at
+ * least 250 000 ids, shorter below) <= 33554432 bytes in all -- the headline sweep (100 atmospheres x 2e7 photons on
+ * one GPU: 244 800 chunks) needs 21 MB of it.  rt_set_tables must have been called before (that call allocates).  All contexts of one GPU share the array: two static sweeps in flight on one GPU at the same time,
+ * on whatever streams or contexts, race; successive calls on one stream are ordered and need no clearing by the
+ * caller. */
+int rt_run_device_static(rt_ctx* ctx, const rt_params* p, void* d_slab_sums, void* d_counts, void* d_mu_hist,
+                         void* d_depth, void* stream);
 
 /* Replay: photon i consumes xi[i*max_draws + j], j = 0,1,... instead of Philox, with its constants
  * given directly (what CreatePhotons would have put in its row).  Used to compare trajectories with

@@ -61,6 +61,15 @@ struct EventPair {
 
 }  // namespace
 
+// Work memory of rt_run_device_static: callers that cannot allocate (HIP graph capture, tight serving loops) get the
+// sweep's queue, plan and chunk partial sums from this array instead of hipMalloc.  Every GPU the library runs on
+// holds its own copy until the process ends; host code never uses the array's name as an address, only the
+// per-device pointer hipGetSymbolAddress returns (rt_create).  All calls on one GPU share it: calls that overlap
+// on one GPU race.
+constexpr size_t kStaticScratchBytes = (size_t)32 << 20;
+constexpr int kStaticMaxAtm = 4096;
+static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
+
 struct rt_ctx {
     int device = 0;
     hipDeviceProp_t prop;
@@ -74,15 +83,14 @@ struct rt_ctx {
     DevBuf<double> d_lam;
     DevBuf<rt::LogTableEntry> d_log_table;
     // sweep workspace
-    DevBuf<rt::AtmPlan> d_plan;
-    DevBuf<uint32_t> d_prefix;
+    DevBuf<unsigned char> d_work;  // plan + item prefix + queue counter + chunk partial sums (see WorkLayout)
+    unsigned char* static_scratch = nullptr;  // this device's copy of the static work array (rt_run_device_static)
+    std::vector<int> order;
     // pinned staging for the plan upload: the copy is asynchronous, `staged` says when the host side may be reused
     void* h_stage = nullptr;
     size_t h_stage_bytes = 0;
     hipEvent_t staged = nullptr;
     bool staged_pending = false;
-    DevBuf<double> d_chunk_sums;
-    DevBuf<unsigned int> d_next;
     // result staging for rt_run / rt_replay
     DevBuf<double> d_slab_sums, d_depth, d_sums;
     DevBuf<unsigned long long> d_counts, d_mu_hist;
@@ -160,13 +168,24 @@ rt::Cfg make_cfg(const rt_ctx* ctx, const rt_params* p) {
     return c;
 }
 
-// Chunk length as a function of the atmosphere's photon count only (so that partial sums,
-// and with them every result bit, are the same for any number of GPUs).
-uint32_t chunk_for(unsigned long long n) {
-    if (n >= 8000000ull) return 16384u;
-    if (n >= 2000000ull) return 8192u;
-    if (n >= 250000ull) return 4096u;
-    return 1024u;
+// Chunk length as a function of the atmosphere's slab length and optical depth only, never of the number of
+// ranks, so that the chunk partial sums -- and with them every result bit -- are the same for any number of GPUs.
+struct ChunkRule {
+    uint32_t thin = 8192u, thick = 8192u;
+    ChunkRule() {
+        if (const char* e = getenv("RT_AMD_CHUNK")) {  // experiments (tools/chunk_sweep.py): "thin,thick"
+            unsigned a = 0, b = 0;
+            if (sscanf(e, "%u,%u", &a, &b) == 2 && a >= 64 && b >= 64 && a <= 65536 && b <= 65536) thin = a, thick = b;
+        }
+    }
+};
+const ChunkRule g_chunk_rule;
+
+uint32_t chunk_for(unsigned long long slab_len, double tau) {
+    // short slabs: shorter chunks, so that a small run still fills the GPU
+    const uint32_t base = slab_len >= 1000000ull ? 16384u : slab_len >= 250000ull ? 8192u : slab_len >= 31250ull ? 4096u : 1024u;
+    const uint32_t cap = tau >= 0.5 ? g_chunk_rule.thick : g_chunk_rule.thin;
+    return base < cap ? base : cap;
 }
 
 void drain_events(rt_ctx* ctx);
@@ -195,6 +214,203 @@ void drain_events(rt_ctx* ctx) {
         }
     }
     ctx->events_used = 0;
+}
+
+
+// Device work memory of one sweep, one block of bytes:
+//   [plan: n_atm PlanEntry][item prefix: n_atm + 1 u32]           uploaded with one copy
+//   [queue counter, 256 bytes]                                    zeroed per sweep
+//   [tally copies: n_copies x n_atm x (RT_NCNT + n_mu_bins + 1) u64]  zeroed per sweep, folded into the caller's arrays
+//   [chunk partial sums: slots x RT_NSUM doubles]                 every slot is written by the wave that walks its chunk
+struct WorkLayout {
+    size_t prefix_off, upload_bytes, next_off, tally_off, tally_words, sums_off, total;
+    uint32_t n_copies;
+};
+
+// Copies of the integer tally arrays: as many as fit kTallyCopyBytes, at most 64.
+constexpr size_t kTallyCopyBytes = (size_t)8 << 20;
+uint32_t tally_copies(size_t words_per_copy) {
+    const size_t fit = kTallyCopyBytes / (8 * (words_per_copy ? words_per_copy : 1));
+    return (uint32_t)(fit < 1 ? 1 : (fit > 64 ? 64 : fit));
+}
+
+WorkLayout work_layout(size_t n_atm, size_t slots, size_t tally_words_per_copy = 0) {
+    WorkLayout w;
+    w.prefix_off = sizeof(rt::PlanEntry) * n_atm;
+    w.upload_bytes = w.prefix_off + sizeof(uint32_t) * (n_atm + 1);
+    w.next_off = (w.upload_bytes + 255) & ~(size_t)255;
+    w.tally_off = w.next_off + 256;
+    w.n_copies = tally_copies(tally_words_per_copy);
+    w.tally_words = tally_words_per_copy * w.n_copies;
+    w.sums_off = (w.tally_off + 8 * w.tally_words + 255) & ~(size_t)255;
+    w.total = w.sums_off + sizeof(double) * slots * RT_NSUM;
+    return w;
+}
+
+// The sweep behind rt_run_device (work memory from the context's growable buffer, kernel timed with events) and
+// rt_run_device_static (work memory = the static device array, nothing allocated, no timing).  Everything that can
+// be refused is checked before the first operation is enqueued.
+int enqueue_sweep(rt_ctx* ctx, const rt_params* p, void* d_slab_sums, void* d_counts, void* d_mu_hist, void* d_depth,
+                  void* stream_v, bool use_static) {
+    if (!ctx) return fail(RT_ERR_INVALID, "ctx is NULL");
+    int rc = check_common(p);
+    if (rc) return rc;
+    if (ctx->n_wl < 1) return fail(RT_ERR_STATE, "rt_set_tables must be called before rt_run");
+    if (p->table_of_atm)
+        for (int a = 0; a < p->n_atm; ++a)
+            if (p->table_of_atm[a] < 0 || p->table_of_atm[a] >= ctx->n_tables)
+                return fail(RT_ERR_INVALID, "atmosphere %d asks for table %d of %d", a, p->table_of_atm[a], ctx->n_tables);
+    if (!d_slab_sums || !d_counts || !d_mu_hist) return fail(RT_ERR_INVALID, "device result buffer is NULL");
+    if (p->n_depth_bins > 0 && !d_depth) return fail(RT_ERR_INVALID, "d_depth is NULL but n_depth_bins > 0");
+    const int n_slabs = p->n_slabs > 0 ? p->n_slabs : 8;
+    const int world = p->world > 0 ? p->world : 1;
+    if (p->rank < 0 || p->rank >= world) return fail(RT_ERR_INVALID, "rank %d not in [0,%d)", p->rank, world);
+    if (n_slabs % world != 0) return fail(RT_ERR_INVALID, "n_slabs (%d) must be a multiple of world (%d)", n_slabs, world);
+    if (use_static && p->n_atm > kStaticMaxAtm)
+        return fail(RT_ERR_LIMIT, "rt_run_device_static takes at most %d atmospheres per call (got %d)", kStaticMaxAtm, p->n_atm);
+    RT_HIP(hipSetDevice(ctx->device));
+    hipStream_t stream = (hipStream_t)stream_v;  // NULL is the (legacy) default stream
+
+    rt::Cfg cfg = make_cfg(ctx, p);
+    if (p->monochromatic_wl != 0.0) {
+        // CreatePhotons rounds the wavelength to 4 decimals and joins on exact equality (MC code.py:394,403-404).
+        const double want = std::round(p->monochromatic_wl * 1e4) / 1e4;
+        for (int i = 0; i < ctx->n_wl; ++i)
+            if (ctx->wl[i] == want || ctx->wl[i] == p->monochromatic_wl) {
+                cfg.mono_index = i;
+                break;
+            }
+        if (cfg.mono_index < 0)
+            return fail(RT_ERR_INVALID,
+                        "monochromatic wavelength %.6g has no exact match in the table (the reference would loop "
+                        "forever on NaN constants)",
+                        p->monochromatic_wl);
+    }
+
+    // ---- plan: heaviest atmospheres first, chunked per slab ----
+    const size_t na = (size_t)p->n_atm;
+    const uint32_t owned = (uint32_t)(n_slabs / world);
+    if (ctx->order.size() < na) ctx->order.resize(na);  // (the static path never gets here: n_atm <= kStaticMaxAtm)
+    int* order = ctx->order.data();
+    std::iota(order, order + na, 0);
+    std::sort(order, order + na, [&](int a, int b) {  // ties keep the caller's order (no scratch memory needed)
+        const double ca = std::min(p->tau_atm[a], 4.0) * (double)p->n_photons[a];
+        const double cb = std::min(p->tau_atm[b], 4.0) * (double)p->n_photons[b];
+        return ca != cb ? ca > cb : a < b;
+    });
+    const WorkLayout up = work_layout(na, 0);
+    if (ctx->staged_pending) {  // the previous call's upload must have left the staging buffer
+        RT_HIP(hipEventSynchronize(ctx->staged));
+        ctx->staged_pending = false;
+    }
+    if (ctx->h_stage_bytes < up.upload_bytes) {  // (never in the static path: the staging buffer holds kStaticMaxAtm)
+        if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+        ctx->h_stage = nullptr;
+        ctx->h_stage_bytes = 0;
+        RT_HIP(hipHostMalloc(&ctx->h_stage, up.upload_bytes, hipHostMallocDefault));
+        ctx->h_stage_bytes = up.upload_bytes;
+    }
+    rt::PlanEntry* plan = static_cast<rt::PlanEntry*>(ctx->h_stage);
+    uint32_t* prefix = reinterpret_cast<uint32_t*>(static_cast<char*>(ctx->h_stage) + up.prefix_off);
+    unsigned long long items = 0;
+    for (int k = 0; k < p->n_atm; ++k) {
+        const int a = order[k];
+        rt::PlanEntry& pl = plan[k];
+        pl.tau = p->tau_atm[a];
+        pl.n_photons = p->n_photons[a];
+        pl.slab_len = (pl.n_photons + (unsigned long long)n_slabs - 1) / (unsigned long long)n_slabs;
+        pl.atm = (uint32_t)a;
+        pl.table = p->table_of_atm ? (uint32_t)p->table_of_atm[a] : 0u;
+        pl.pad_ = 0u;
+        pl.chunk = chunk_for(pl.slab_len, pl.tau);
+        pl.chunks = (uint32_t)((pl.slab_len + pl.chunk - 1) / pl.chunk);
+        if (pl.chunks == 0) pl.chunks = 1;  // an empty atmosphere still has one (empty) chunk per slab
+        pl.slot_base = (uint32_t)items;
+        prefix[k] = (uint32_t)items;
+        items += (unsigned long long)owned * pl.chunks;  // one slot per queued chunk
+        if (items > 0x7fffffffull) return fail(RT_ERR_LIMIT, "too many work items (%llu)", items);
+    }
+    prefix[p->n_atm] = (uint32_t)items;
+    const size_t nmu = (size_t)p->n_mu_bins + 1;
+    const WorkLayout lay = work_layout(na, (size_t)items, na * (RT_NCNT + nmu));
+
+    unsigned char* work = nullptr;
+    if (use_static) {
+        if (lay.total > kStaticScratchBytes)
+            return fail(RT_ERR_LIMIT,
+                        "rt_run_device_static: this sweep needs %zu bytes of work memory (%llu chunks), the static array "
+                        "holds %zu; use rt_run_device", lay.total, items, kStaticScratchBytes);
+        work = ctx->static_scratch;
+    } else {
+        RT_HIP(ctx->d_work.reserve(lay.total));
+        work = ctx->d_work.p;
+    }
+    unsigned int* d_next = reinterpret_cast<unsigned int*>(work + lay.next_off);
+    double* d_chunk_sums = reinterpret_cast<double*>(work + lay.sums_off);
+    unsigned long long* d_tally = reinterpret_cast<unsigned long long*>(work + lay.tally_off);
+    unsigned long long* d_count_copies = d_tally;                                           // [n_copies][n_atm][RT_NCNT]
+    unsigned long long* d_hist_copies = d_tally + (size_t)lay.n_copies * na * RT_NCNT;     // [n_copies][n_atm][nmu]
+
+    rt::Sweep sw;
+    sw.plan = reinterpret_cast<const rt::PlanEntry*>(work);
+    sw.item_prefix = reinterpret_cast<const uint32_t*>(work + lay.prefix_off);
+    sw.n_atm = (uint32_t)p->n_atm;
+    sw.n_items = (uint32_t)items;
+    sw.n_interleaved = 0u;
+    sw.row_len = 0u;
+    sw.rank = (uint32_t)p->rank;
+    sw.world = (uint32_t)world;
+    sw.n_slabs = (uint32_t)n_slabs;
+    sw.owned_slabs = owned;
+    sw.n_copies = lay.n_copies;
+
+    const bool fast = p->loop_order == RT_ORDER_MC && p->boundary == RT_BOUNDARY_REFLECT &&
+                      p->scatter == RT_SCATTER_HG && p->n_depth_bins == 0 && !p->abs_only &&
+                      p->geometry == RT_GEOM_SLAB;
+    const size_t lds = rt::walk_lds_bytes(cfg.n_mu_bins, fast ? 0 : cfg.n_depth_bins);  // within the limit: check_common
+    const bool packed = p->rng_mode == RT_RNG_PHILOX32X4;
+    const bool plain = fast && !packed && !p->rand_mu && cfg.mono_index < 0;  // the reference's defaults throughout
+    const int variant = plain ? 4 : (fast ? 1 : 0) + (packed ? 2 : 0);
+    int& cached = ctx->blocks_per_cu[variant];
+    if (cached <= 0 || ctx->blocks_lds[variant] != lds) {
+        cached = rt::walk_max_blocks_per_cu(fast, packed, plain, lds);
+        ctx->blocks_lds[variant] = lds;
+    }
+    const int per_cu = cached;
+    long long grid = (long long)ctx->prop.multiProcessorCount * per_cu;
+    const long long need = ((long long)items + 3) / 4;
+    if (grid > need) grid = need;
+    if (grid < 1) grid = 1;
+
+    {   // the cheapest items (end of the list) stay in order for the end of the launch: two per resident wave
+        // (measured: 0 costs 2 %, 1 to 8 per wave are equal)
+        const unsigned long long tail = std::min<unsigned long long>(items / 8, (unsigned long long)grid * 4 * 2);
+        const unsigned long long rows = rt::kQueueRows;
+        // worth it from about 8 items per resident wave on; a shorter launch is decided by the balance of its end,
+        // which the plain heaviest-first order serves best (measured: -4 % at 5 items per wave, +1.5 % at 10, +3.5 % at 24)
+        if (items >= (unsigned long long)grid * 4 * 8 && items - tail >= rows * 8) {
+            sw.row_len = (uint32_t)((items - tail) / rows);
+            sw.n_interleaved = (uint32_t)(sw.row_len * rows);
+        }
+    }
+
+    // ---- device work: one upload, one kernel that zeroes what the walk accumulates into, the walk, slab sums and tally fold
+    RT_HIP(hipMemcpyAsync(work, ctx->h_stage, lay.upload_bytes, hipMemcpyHostToDevice, stream));
+    RT_HIP(hipEventRecord(ctx->staged, stream));
+    ctx->staged_pending = true;
+    RT_HIP(rt::launch_zero_results(d_next, d_tally, lay.tally_words, (double*)d_depth, 2 * na * (size_t)p->n_depth_bins, stream));
+    EventPair* ev = nullptr;
+    if (!use_static) {  // timing events are created on demand, which allocates: the static path is not timed
+        RT_HIP(next_events(ctx, &ev));
+        RT_HIP(hipEventRecord(ev->a, stream));
+    }
+    RT_HIP(rt::launch_walk(cfg, sw, fast, packed, plain, (int)grid, stream, d_next, d_chunk_sums, d_count_copies,
+                           d_hist_copies, (double*)d_depth));
+    if (ev) RT_HIP(hipEventRecord(ev->b, stream));
+    RT_HIP(rt::launch_slab_reduce(sw, d_chunk_sums, (double*)d_slab_sums, stream));
+    RT_HIP(rt::launch_fold_tallies(d_count_copies, lay.n_copies, na * RT_NCNT, (unsigned long long*)d_counts, stream));
+    RT_HIP(rt::launch_fold_tallies(d_hist_copies, lay.n_copies, na * nmu, (unsigned long long*)d_mu_hist, stream));
+    return RT_OK;
 }
 
 }  // namespace
@@ -235,6 +451,22 @@ int rt_create(rt_ctx** out, int device_id) {
         delete ctx;
         return fail(RT_ERR_DEVICE, "hipStreamCreate / hipEventCreate: %s", hipGetErrorString(e));
     }
+    // this device's address of the static work array, and host staging for the largest plan the static path accepts
+    {
+        void* sp = nullptr;
+        e = hipGetSymbolAddress(&sp, HIP_SYMBOL(scratch));
+        if (e == hipSuccess) {
+            ctx->static_scratch = static_cast<unsigned char*>(sp);
+            ctx->h_stage_bytes = work_layout((size_t)kStaticMaxAtm, 0).upload_bytes;
+            e = hipHostMalloc(&ctx->h_stage, ctx->h_stage_bytes, hipHostMallocDefault);
+            if (e != hipSuccess) ctx->h_stage_bytes = 0;
+        }
+        if (e != hipSuccess) {
+            rt_destroy(ctx);
+            return fail(RT_ERR_DEVICE, "static work array / staging buffer: %s", hipGetErrorString(e));
+        }
+        ctx->order.resize(kStaticMaxAtm);
+    }
     // logarithm table for the kernels' ln(): c_j = 1 + (j + 1/2)/128, inv_c = fl(1/c_j), l = -ln(inv_c)
     std::vector<rt::LogTableEntry> tab(rt::kLogTableEntries);
     for (int j = 0; j < rt::kLogTableEntries; ++j) {
@@ -265,12 +497,9 @@ int rt_destroy(rt_ctx* ctx) {
     ctx->d_alias.release();
     ctx->d_lam.release();
     ctx->d_log_table.release();
-    ctx->d_plan.release();
-    ctx->d_prefix.release();
+    ctx->d_work.release();
     if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
     if (ctx->staged) (void)hipEventDestroy(ctx->staged);
-    ctx->d_chunk_sums.release();
-    ctx->d_next.release();
     ctx->d_slab_sums.release();
     ctx->d_depth.release();
     ctx->d_sums.release();
@@ -360,151 +589,12 @@ int rt_set_tables(rt_ctx* ctx, int32_t n_wl, const double* wl, const double* g, 
 
 int rt_run_device(rt_ctx* ctx, const rt_params* p, void* d_slab_sums, void* d_counts, void* d_mu_hist, void* d_depth,
                   void* stream_v) {
-    if (!ctx) return fail(RT_ERR_INVALID, "ctx is NULL");
-    int rc = check_common(p);
-    if (rc) return rc;
-    if (ctx->n_wl < 1) return fail(RT_ERR_STATE, "rt_set_tables must be called before rt_run");
-    if (p->table_of_atm)
-        for (int a = 0; a < p->n_atm; ++a)
-            if (p->table_of_atm[a] < 0 || p->table_of_atm[a] >= ctx->n_tables)
-                return fail(RT_ERR_INVALID, "atmosphere %d asks for table %d of %d", a, p->table_of_atm[a], ctx->n_tables);
-    if (!d_slab_sums || !d_counts || !d_mu_hist) return fail(RT_ERR_INVALID, "device result buffer is NULL");
-    if (p->n_depth_bins > 0 && !d_depth) return fail(RT_ERR_INVALID, "d_depth is NULL but n_depth_bins > 0");
-    const int n_slabs = p->n_slabs > 0 ? p->n_slabs : 8;
-    const int world = p->world > 0 ? p->world : 1;
-    if (p->rank < 0 || p->rank >= world) return fail(RT_ERR_INVALID, "rank %d not in [0,%d)", p->rank, world);
-    if (n_slabs % world != 0) return fail(RT_ERR_INVALID, "n_slabs (%d) must be a multiple of world (%d)", n_slabs, world);
-    RT_HIP(hipSetDevice(ctx->device));
-    hipStream_t stream = (hipStream_t)stream_v;  // NULL is the (legacy) default stream
+    return enqueue_sweep(ctx, p, d_slab_sums, d_counts, d_mu_hist, d_depth, stream_v, false);
+}
 
-    rt::Cfg cfg = make_cfg(ctx, p);
-    if (p->monochromatic_wl != 0.0) {
-        // CreatePhotons rounds the wavelength to 4 decimals and joins on exact equality (MC code.py:394,403-404).
-        const double want = std::round(p->monochromatic_wl * 1e4) / 1e4;
-        for (int i = 0; i < ctx->n_wl; ++i)
-            if (ctx->wl[i] == want || ctx->wl[i] == p->monochromatic_wl) {
-                cfg.mono_index = i;
-                break;
-            }
-        if (cfg.mono_index < 0)
-            return fail(RT_ERR_INVALID,
-                        "monochromatic wavelength %.6g has no exact match in the table (the reference would loop "
-                        "forever on NaN constants)",
-                        p->monochromatic_wl);
-    }
-
-    // ---- plan: heaviest atmospheres first, chunked per slab ----
-    const uint32_t owned = (uint32_t)(n_slabs / world);
-    std::vector<int> order((size_t)p->n_atm);
-    std::iota(order.begin(), order.end(), 0);
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
-        const double ca = std::min(p->tau_atm[a], 4.0) * (double)p->n_photons[a];
-        const double cb = std::min(p->tau_atm[b], 4.0) * (double)p->n_photons[b];
-        return ca > cb;
-    });
-    const size_t plan_bytes = sizeof(rt::AtmPlan) * (size_t)p->n_atm;
-    const size_t prefix_bytes = sizeof(uint32_t) * ((size_t)p->n_atm + 1);
-    if (ctx->staged_pending) {  // the previous call's upload must have left the staging buffer
-        RT_HIP(hipEventSynchronize(ctx->staged));
-        ctx->staged_pending = false;
-    }
-    if (ctx->h_stage_bytes < plan_bytes + prefix_bytes) {
-        if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
-        ctx->h_stage = nullptr;
-        ctx->h_stage_bytes = 0;
-        RT_HIP(hipHostMalloc(&ctx->h_stage, plan_bytes + prefix_bytes, hipHostMallocDefault));
-        ctx->h_stage_bytes = plan_bytes + prefix_bytes;
-    }
-    rt::AtmPlan* plan = static_cast<rt::AtmPlan*>(ctx->h_stage);
-    uint32_t* prefix = reinterpret_cast<uint32_t*>(static_cast<char*>(ctx->h_stage) + plan_bytes);
-    unsigned long long slots = 0, items = 0;
-    for (int k = 0; k < p->n_atm; ++k) {
-        const int a = order[k];
-        rt::AtmPlan& pl = plan[k];
-        pl.tau = p->tau_atm[a];
-        pl.n_photons = p->n_photons[a];
-        pl.slab_len = (pl.n_photons + (unsigned long long)n_slabs - 1) / (unsigned long long)n_slabs;
-        pl.atm = (uint32_t)a;
-        pl.table = p->table_of_atm ? (uint32_t)p->table_of_atm[a] : 0u;
-        pl.pad_ = 0u;
-        pl.chunk = chunk_for(pl.n_photons);
-        pl.chunks_per_slab = (uint32_t)((pl.slab_len + pl.chunk - 1) / pl.chunk);
-        if (pl.chunks_per_slab == 0) pl.chunks_per_slab = 1;
-        pl.slot_base = (uint32_t)slots;
-        prefix[k] = (uint32_t)items;
-        slots += (unsigned long long)owned * pl.chunks_per_slab;
-        items += (unsigned long long)owned * pl.chunks_per_slab;
-        if (items > 0x7fffffffull) return fail(RT_ERR_LIMIT, "too many work items (%llu)", items);
-    }
-    prefix[p->n_atm] = (uint32_t)items;
-
-    RT_HIP(ctx->d_plan.reserve((size_t)p->n_atm));
-    RT_HIP(ctx->d_prefix.reserve((size_t)p->n_atm + 1));
-    RT_HIP(ctx->d_chunk_sums.reserve((size_t)slots * RT_NSUM));
-    RT_HIP(ctx->d_next.reserve(1));
-    RT_HIP(hipMemcpyAsync(ctx->d_plan.p, plan, plan_bytes, hipMemcpyHostToDevice, stream));
-    RT_HIP(hipMemcpyAsync(ctx->d_prefix.p, prefix, prefix_bytes, hipMemcpyHostToDevice, stream));
-    RT_HIP(hipEventRecord(ctx->staged, stream));
-    ctx->staged_pending = true;
-
-    rt::Sweep sw;
-    sw.plan = ctx->d_plan.p;
-    sw.item_prefix = ctx->d_prefix.p;
-    sw.n_atm = (uint32_t)p->n_atm;
-    sw.n_items = (uint32_t)items;
-    sw.n_interleaved = 0u;
-    sw.row_len = 0u;
-    sw.rank = (uint32_t)p->rank;
-    sw.world = (uint32_t)world;
-    sw.n_slabs = (uint32_t)n_slabs;
-    sw.owned_slabs = owned;
-
-    const size_t nmu = (size_t)p->n_mu_bins + 1;
-    RT_HIP(hipMemsetAsync(ctx->d_next.p, 0, sizeof(unsigned int), stream));
-    RT_HIP(hipMemsetAsync(ctx->d_chunk_sums.p, 0, sizeof(double) * (size_t)slots * RT_NSUM, stream));
-    RT_HIP(hipMemsetAsync(d_slab_sums, 0, sizeof(double) * (size_t)p->n_atm * n_slabs * RT_NSUM, stream));
-    RT_HIP(hipMemsetAsync(d_counts, 0, sizeof(unsigned long long) * (size_t)p->n_atm * RT_NCNT, stream));
-    RT_HIP(hipMemsetAsync(d_mu_hist, 0, sizeof(unsigned long long) * (size_t)p->n_atm * nmu, stream));
-    if (p->n_depth_bins > 0)
-        RT_HIP(hipMemsetAsync(d_depth, 0, sizeof(double) * 2 * (size_t)p->n_atm * p->n_depth_bins, stream));
-
-    const bool fast = p->loop_order == RT_ORDER_MC && p->boundary == RT_BOUNDARY_REFLECT &&
-                      p->scatter == RT_SCATTER_HG && p->n_depth_bins == 0 && !p->abs_only &&
-                      p->geometry == RT_GEOM_SLAB;
-    const size_t lds = rt::walk_lds_bytes(cfg.n_mu_bins, fast ? 0 : cfg.n_depth_bins);  // within the limit: check_common
-    const bool packed = p->rng_mode == RT_RNG_PHILOX32X4;
-    const bool plain = fast && !packed && !p->rand_mu && cfg.mono_index < 0;  // the reference's defaults throughout
-    const int variant = plain ? 4 : (fast ? 1 : 0) + (packed ? 2 : 0);
-    int& cached = ctx->blocks_per_cu[variant];
-    if (cached <= 0 || ctx->blocks_lds[variant] != lds) {
-        cached = rt::walk_max_blocks_per_cu(fast, packed, plain, lds);
-        ctx->blocks_lds[variant] = lds;
-    }
-    const int per_cu = cached;
-    long long grid = (long long)ctx->prop.multiProcessorCount * per_cu;
-    const long long need = ((long long)items + 3) / 4;
-    if (grid > need) grid = need;
-    if (grid < 1) grid = 1;
-
-    {   // the cheapest items (end of the list) stay in order for the end of the launch: two per resident wave
-        // (measured: 0 costs 2 %, 1 to 8 per wave are equal)
-        const unsigned long long tail = std::min<unsigned long long>(items / 8, (unsigned long long)grid * 4 * 2);
-        const unsigned long long rows = rt::kQueueRows;
-        // worth it from about 8 items per resident wave on; a shorter launch is decided by the balance of its end,
-        // which the plain heaviest-first order serves best (measured: -4 % at 5 items per wave, +1.5 % at 10, +3.5 % at 24)
-        if (items >= (unsigned long long)grid * 4 * 8 && items - tail >= rows * 8) {
-            sw.row_len = (uint32_t)((items - tail) / rows);
-            sw.n_interleaved = (uint32_t)(sw.row_len * rows);
-        }
-    }
-    EventPair* ev = nullptr;
-    RT_HIP(next_events(ctx, &ev));
-    RT_HIP(hipEventRecord(ev->a, stream));
-    RT_HIP(rt::launch_walk(cfg, sw, fast, packed, plain, (int)grid, stream, ctx->d_next.p, ctx->d_chunk_sums.p,
-                           (unsigned long long*)d_counts, (unsigned long long*)d_mu_hist, (double*)d_depth));
-    RT_HIP(hipEventRecord(ev->b, stream));
-    RT_HIP(rt::launch_slab_reduce(sw, ctx->d_chunk_sums.p, (double*)d_slab_sums, stream));
-    return RT_OK;
+int rt_run_device_static(rt_ctx* ctx, const rt_params* p, void* d_slab_sums, void* d_counts, void* d_mu_hist,
+                         void* d_depth, void* stream_v) {
+    return enqueue_sweep(ctx, p, d_slab_sums, d_counts, d_mu_hist, d_depth, stream_v, true);
 }
 
 int rt_run(rt_ctx* ctx, const rt_params* p, rt_tallies* out) {

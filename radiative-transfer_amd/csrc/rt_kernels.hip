@@ -14,6 +14,7 @@
 //
 // Replaces RunPhotons (MC code.py:620-779, Numpy_random_walk.py:280-408) and the
 // atmosphere loop of runMC (MC code.py:1056-1062).
+#include <algorithm>
 #include <type_traits>
 
 #include "rt_kernels.hpp"
@@ -21,6 +22,15 @@
 namespace rt {
 
 constexpr int kWavesPerBlock = kWalkBlock / 64;
+
+#ifdef RT_WAVE_TRACE
+// Tooling build only (tools/wave_trace.py): per wave of the last walk launch, 100 MHz clock at its first queue pop, at
+// the start of its last chunk and at its end, and the number of chunks it walked.
+__device__ unsigned long long g_wave_trace[4 * 8192];
+extern "C" int rt_debug_wave_trace(unsigned long long* out, int n_waves) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_trace), sizeof(unsigned long long) * 4 * (size_t)n_waves);
+}
+#endif
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -114,18 +124,24 @@ __device__ __forceinline__ bool pop_item(const Sweep& sw, unsigned int* d_next, 
     q = __builtin_amdgcn_readfirstlane(q);
     if (q >= sw.n_items) return false;
     if (q < sw.n_interleaved) q = (q & (kQueueRows - 1u)) * sw.row_len + (q >> kQueueRowsLog2);
-    int lo = 0, hi = (int)sw.n_atm;  // sorted position with item_prefix[lo] <= q < item_prefix[lo+1]
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (sw.item_prefix[mid] <= q)
-            lo = mid;
-        else
-            hi = mid;
+    // Sorted position lo with item_prefix[lo] <= q < item_prefix[lo+1], searched 64 ways at a time: every lane
+    // reads one entry of the candidate range, a ballot picks the sub-range -- two dependent loads for up to 4096
+    // atmospheres where a binary search has twelve (the wave idles through each of them once per chunk).
+    uint32_t lo = 0u, span = sw.n_atm;  // candidates lo .. lo + span - 1; item_prefix[lo] <= q holds throughout
+    while (span > 1u) {
+        const uint32_t step = (span + 63u) >> 6;
+        const uint32_t idx = lo + (uint32_t)lane * step;
+        const uint32_t v = idx < lo + span ? sw.item_prefix[idx] : 0xffffffffu;
+        const uint32_t below = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(v <= q));  // >= 1: lane 0 reads item_prefix[lo]
+        const uint32_t end = lo + span;
+        lo += (below - 1u) * step;
+        span = end - lo < step ? end - lo : step;
     }
-    const AtmPlan plan = sw.plan[lo];
+    lo = __builtin_amdgcn_readfirstlane(lo);
+    const PlanEntry plan = sw.plan[lo];
     const unsigned int local = q - sw.item_prefix[lo];
-    const unsigned int j = local / plan.chunks_per_slab;  // ordinal among the slabs this rank owns
-    const unsigned int c = local - j * plan.chunks_per_slab;
+    const unsigned int j = local / plan.chunks;  // ordinal among the slabs this rank owns
+    const unsigned int c = local - j * plan.chunks;
     const unsigned long long slab = (unsigned long long)sw.rank + (unsigned long long)j * sw.world;
     const unsigned long long slab_lo = slab * plan.slab_len;
     unsigned long long slab_hi = slab_lo + plan.slab_len;
@@ -137,7 +153,7 @@ __device__ __forceinline__ bool pop_item(const Sweep& sw, unsigned int* d_next, 
     it.tau = __longlong_as_double((long long)uniform64((unsigned long long)__double_as_longlong(plan.tau)));
     it.atm = __builtin_amdgcn_readfirstlane(plan.atm);
     it.table = __builtin_amdgcn_readfirstlane(plan.table);
-    it.slot = (size_t)uniform64((unsigned long long)plan.slot_base + (unsigned long long)j * plan.chunks_per_slab + c);
+    it.slot = (size_t)uniform64((unsigned long long)plan.slot_base + (unsigned long long)j * plan.chunks + c);
     return true;
 }
 
@@ -198,6 +214,7 @@ __global__ __launch_bounds__(kWalkBlock) void walk_kernel(const Cfg cfg0, const 
                                                            unsigned long long* __restrict__ d_counts,
                                                            unsigned long long* __restrict__ d_mu_hist,
                                                            double* __restrict__ d_depth) {
+    // d_counts [n_copies][n_atm][RT_NCNT], d_mu_hist [n_copies][n_atm][n_mu_bins + 1]
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -206,9 +223,24 @@ __global__ __launch_bounds__(kWalkBlock) void walk_kernel(const Cfg cfg0, const 
     const Hist hist = wave_hist(lds_raw, wave, nmu, nd);
     stage_log_table(cfg0, lds_raw);
     clear_hist(hist, lane, nmu, nd);
+    // Integer tallies and the escape histogram go to one of n_copies copies of the tally arrays (folded afterwards):
+    // with one copy, all the waves that finish chunks of the same atmosphere queue up on the same few cache lines.
+    {
+        const uint32_t copy = ((uint32_t)blockIdx.x * kWavesPerBlock + (uint32_t)wave) % sw.n_copies;
+        d_counts += (size_t)copy * sw.n_atm * RT_NCNT;
+        d_mu_hist += (size_t)copy * sw.n_atm * (size_t)nmu;
+    }
 
+#ifdef RT_WAVE_TRACE
+    const unsigned long long t_begin = wall_clock64();
+    unsigned long long t_last = t_begin, n_done = 0ull;
+#endif
     WorkItem it;
     while (pop_item(sw, d_next, lane, it)) {
+#ifdef RT_WAVE_TRACE
+        t_last = wall_clock64();
+        ++n_done;
+#endif
         const double tau = it.tau;
         Cfg cfg = cfg0;  // this atmosphere's table (wave-uniform)
         cfg.table_base = (int32_t)(it.table * (uint32_t)cfg0.n_wl);
@@ -371,31 +403,65 @@ __global__ __launch_bounds__(kWalkBlock) void walk_kernel(const Cfg cfg0, const 
             store_chunk(acc, it, hist, lane, nmu, nd, sw.n_atm, d_chunk_sums, d_counts, d_mu_hist, d_depth);
         }
     }
+#ifdef RT_WAVE_TRACE
+    if (lane == 0) {
+        unsigned long long* t = g_wave_trace + 4 * (size_t)(blockIdx.x * kWavesPerBlock + wave);
+        t[0] = t_begin;
+        t[1] = t_last;  // start of this wave's last chunk
+        t[2] = wall_clock64();
+        t[3] = n_done;
+    }
+#endif
 }
 
-// One thread per (sorted atmosphere, owned slab, tally): chunk partials summed in chunk order.
-__global__ void slab_reduce_kernel(const Sweep sw, const double* __restrict__ d_chunk_sums,
-                                   double* __restrict__ d_slab_sums) {
-    const unsigned int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const unsigned int per_atm = sw.owned_slabs * RT_NSUM;
-    if (t >= sw.n_atm * per_atm) return;
-    const unsigned int a = t / per_atm;
-    const unsigned int r = t - a * per_atm;
-    const unsigned int j = r / RT_NSUM;
-    const unsigned int k = r - j * RT_NSUM;
-    const AtmPlan plan = sw.plan[a];
-    const unsigned int slab = sw.rank + j * sw.world;
-    if (slab >= sw.n_slabs) return;
-    const double* src = d_chunk_sums + ((size_t)plan.slot_base + (size_t)j * plan.chunks_per_slab) * RT_NSUM + k;
-    double s = 0.0;
-    // chunks beyond the end of the atmosphere were never queued: count the real ones
-    const unsigned long long slab_lo = (unsigned long long)slab * plan.slab_len;
-    unsigned long long slab_hi = slab_lo + plan.slab_len;
-    slab_hi = slab_hi < plan.n_photons ? slab_hi : plan.n_photons;
-    const unsigned long long len = slab_hi > slab_lo ? slab_hi - slab_lo : 0ull;
-    const unsigned int n_chunks = (unsigned int)((len + plan.chunk - 1) / plan.chunk);
-    for (unsigned int c = 0; c < n_chunks; ++c) s += src[(size_t)c * RT_NSUM];
-    d_slab_sums[((size_t)plan.atm * sw.n_slabs + slab) * RT_NSUM + k] = s;
+// Zeroes what a sweep accumulates into with atomics: the queue counter, the tally copies and the depth arrays.
+__global__ void zero_results_kernel(unsigned int* __restrict__ d_next, unsigned long long* __restrict__ a, size_t na,
+                                    unsigned long long* __restrict__ b, size_t nb) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t == 0) *d_next = 0u;
+    for (size_t i = t; i < na; i += stride) a[i] = 0ull;
+    for (size_t i = t; i < nb; i += stride) b[i] = 0ull;
+}
+
+// out[i] = sum over the copies of in[c * n + i] (integers: any order gives the same bits).
+__global__ void fold_tallies_kernel(const unsigned long long* __restrict__ in, uint32_t n_copies, size_t n,
+                                    unsigned long long* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    unsigned long long s = 0ull;
+    for (uint32_t c = 0; c < n_copies; ++c) s += in[(size_t)c * n + i];
+    out[i] = s;
+}
+
+// One wave per (atmosphere, slab); the slabs of other ranks are set to zero.  An owned slab's chunk partials are added in a fixed
+// shape -- lane l takes the slots l, l + 64, ... in order, then the lanes are combined by the butterfly -- that
+// depends on the slab's chunk count only.  Every slot of the range was written by the walk kernel (a chunk beyond
+// the end of a short last slab holds zeros).
+__global__ __launch_bounds__(64) void slab_reduce_kernel(const Sweep sw, const double* __restrict__ d_chunk_sums,
+                                                         double* __restrict__ d_slab_sums) {
+    const unsigned int a = blockIdx.x / sw.n_slabs;
+    const unsigned int slab = blockIdx.x - a * sw.n_slabs;
+    const int lane = threadIdx.x;
+    const PlanEntry plan = sw.plan[a];
+    if (slab % sw.world != sw.rank) {
+        if (lane < RT_NSUM) d_slab_sums[((size_t)plan.atm * sw.n_slabs + slab) * RT_NSUM + lane] = 0.0;
+        return;
+    }
+    const unsigned int j = slab / sw.world;  // ordinal among the slabs this rank owns
+    const double* src = d_chunk_sums + ((size_t)plan.slot_base + (size_t)j * plan.chunks) * RT_NSUM;
+    double s[RT_NSUM];
+#pragma unroll
+    for (int k = 0; k < RT_NSUM; ++k) s[k] = 0.0;
+    for (unsigned int c = (unsigned int)lane; c < plan.chunks; c += 64u) {
+#pragma unroll
+        for (int k = 0; k < RT_NSUM; ++k) s[k] += src[(size_t)c * RT_NSUM + k];
+    }
+#pragma unroll
+    for (int k = 0; k < RT_NSUM; ++k) {
+        const double v = wave_sum(s[k]);
+        if (lane == 0) d_slab_sums[((size_t)plan.atm * sw.n_slabs + slab) * RT_NSUM + k] = v;
+    }
 }
 
 __global__ __launch_bounds__(kWalkBlock) void replay_kernel(const Cfg cfg, const double tau, const long long n,
@@ -611,10 +677,26 @@ hipError_t launch_walk(const Cfg& cfg, const Sweep& sw, bool fast, bool packed, 
     return hipGetLastError();
 }
 
+hipError_t launch_zero_results(unsigned int* d_next, unsigned long long* d_tallies, size_t n_tallies, double* d_depth,
+                               size_t n_depth, hipStream_t stream) {
+    size_t grid = (std::max(n_tallies, n_depth) + 255) / 256;
+    grid = grid < 1 ? 1 : (grid > 2048 ? 2048 : grid);
+    zero_results_kernel<<<(unsigned int)grid, 256, 0, stream>>>(d_next, d_tallies, n_tallies,
+                                                                reinterpret_cast<unsigned long long*>(d_depth), n_depth);
+    return hipGetLastError();
+}
+
+hipError_t launch_fold_tallies(const unsigned long long* d_copies, uint32_t n_copies, size_t n, unsigned long long* d_out,
+                               hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    fold_tallies_kernel<<<(unsigned int)((n + 255) / 256), 256, 0, stream>>>(d_copies, n_copies, n, d_out);
+    return hipGetLastError();
+}
+
 hipError_t launch_slab_reduce(const Sweep& sw, const double* d_chunk_sums, double* d_slab_sums, hipStream_t stream) {
-    const unsigned int total = sw.n_atm * sw.owned_slabs * RT_NSUM;
+    const unsigned int total = sw.n_atm * sw.n_slabs;
     if (total == 0) return hipSuccess;
-    slab_reduce_kernel<<<(total + 255) / 256, 256, 0, stream>>>(sw, d_chunk_sums, d_slab_sums);
+    slab_reduce_kernel<<<total, 64, 0, stream>>>(sw, d_chunk_sums, d_slab_sums);
     return hipGetLastError();
 }
 

@@ -5,32 +5,34 @@
 
 namespace rt {
 
-// How one atmosphere's photon-id range [0, n_photons) is cut up.  The cut depends only on
-// n_photons and n_slabs, never on the number of GPUs:
+// How one atmosphere's photon-id range [0, n_photons) is cut up.  The cut depends only on n_photons and n_slabs,
+// never on the number of GPUs:
 //   slab s   = ids [s*slab_len, min((s+1)*slab_len, n_photons))        s = 0..n_slabs-1
 //   chunk c  = ids [slab_lo + c*chunk, ...) inside a slab               one wave walks one chunk
-// A rank owns the slabs s with s % world == rank; its chunk partials live at
-//   slot_base + j*chunks_per_slab + c   where j = (s - rank) / world.
-struct AtmPlan {
+// A rank owns the slabs s with s % world == rank; the partial sums of the chunks of its j-th slab
+// (j = (s - rank) / world) live at slots  slot_base + j*chunks + c.
+struct PlanEntry {
     double tau;
     unsigned long long n_photons;
     unsigned long long slab_len;
-    uint32_t atm;              // index of this atmosphere in the caller's arrays
-    uint32_t chunk;            // photon ids per chunk
-    uint32_t chunks_per_slab;  // ceil(slab_len / chunk)
-    uint32_t slot_base;        // first chunk-partial slot of this atmosphere
-    uint32_t table;            // which of the context's tables this atmosphere uses
+    uint32_t atm;        // index of this atmosphere in the caller's arrays
+    uint32_t chunk;      // photon ids per chunk
+    uint32_t chunks;     // chunks per slab: ceil(slab_len / chunk)
+    uint32_t slot_base;  // first chunk-partial slot of this atmosphere
+    uint32_t table;      // which of the context's tables this atmosphere uses
     uint32_t pad_;
 };
+static_assert(sizeof(PlanEntry) == 48, "plan entries are uploaded as raw bytes");
 
 struct Sweep {
-    const AtmPlan* plan;          // device, n_atm entries, heaviest atmospheres first
-    const uint32_t* item_prefix;  // device, n_atm + 1 entries: first queue index of each sorted atmosphere
+    const PlanEntry* plan;        // device, n_atm entries, heaviest atmospheres first
+    const uint32_t* item_prefix;  // device, n_atm + 1 entries: first queue index of each entry
     uint32_t n_atm;
     uint32_t n_items;
     uint32_t rank, world;
     uint32_t n_slabs, owned_slabs;
-    // Order in which the queue hands out the items of the heaviest-first list: positions below n_interleaved
+    uint32_t n_copies;  // copies of the integer tally arrays the waves spread their atomics over
+    // Order in which the queue hands out the items of the list: positions below n_interleaved
     // (= kQueueRows * row_len) go through the list in kQueueRows rows at once, position q -> item
     // (q % kQueueRows) * row_len + q / kQueueRows, so that thick and thin atmospheres are in flight together
     // from the first wave to (almost) the last; the remaining items, the cheapest of the list, follow in order
@@ -52,8 +54,16 @@ int walk_max_blocks_per_cu(bool fast, bool packed, bool plain, size_t lds_bytes)
 
 hipError_t launch_walk(const Cfg& cfg, const Sweep& sw, bool fast, bool packed, bool plain, int grid, hipStream_t stream,
                        unsigned int* d_next, double* d_chunk_sums, unsigned long long* d_counts,
-                       unsigned long long* d_mu_hist, double* d_depth);
+                       unsigned long long* d_mu_hist, double* d_depth);  // d_counts / d_mu_hist: sw.n_copies copies each
 
+// *d_next = 0, the tally copies and the depth arrays zeroed (lengths in 64-bit words; d_depth may be null with n_depth = 0)
+hipError_t launch_zero_results(unsigned int* d_next, unsigned long long* d_tallies, size_t n_tallies, double* d_depth,
+                               size_t n_depth, hipStream_t stream);
+// d_out[i] = sum over c < n_copies of d_copies[c * n + i]
+hipError_t launch_fold_tallies(const unsigned long long* d_copies, uint32_t n_copies, size_t n, unsigned long long* d_out,
+                               hipStream_t stream);
+
+// writes every slab of every atmosphere: the owned ones from their chunk partials, the others zero
 hipError_t launch_slab_reduce(const Sweep& sw, const double* d_chunk_sums, double* d_slab_sums, hipStream_t stream);
 
 hipError_t launch_replay(const Cfg& cfg, double tau, long long n, int max_draws, const double* d_xi,

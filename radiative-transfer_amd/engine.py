@@ -172,9 +172,11 @@ class Engine:
         self._check(self._lib.rt_run(self._ctx, C.byref(params), C.byref(res._c)))
         return res
 
-    def run_device(self, params, slab_sums_ptr, counts_ptr, mu_hist_ptr, depth_ptr=None, stream=None):
-        """Enqueue a sweep whose results stay in caller-owned device buffers (raw addresses)."""
-        self._check(self._lib.rt_run_device(self._ctx, C.byref(params), C.c_void_p(slab_sums_ptr),
+    def run_device(self, params, slab_sums_ptr, counts_ptr, mu_hist_ptr, depth_ptr=None, stream=None, static=False):
+        """Enqueue a sweep whose results stay in caller-owned device buffers (raw addresses).  `static`: the entry
+        point that allocates nothing (rt_run_device_static: work memory in the library's static device array)."""
+        fn = self._lib.rt_run_device_static if static else self._lib.rt_run_device
+        self._check(fn(self._ctx, C.byref(params), C.c_void_p(slab_sums_ptr),
                                             C.c_void_p(counts_ptr), C.c_void_p(mu_hist_ptr),
                                             C.c_void_p(depth_ptr) if depth_ptr else None,
                                             C.c_void_p(stream) if stream else None))

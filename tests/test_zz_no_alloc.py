@@ -1,0 +1,65 @@
+"""rt_run_device_static: the sweep entry point that allocates nothing (its work memory is a static device array).
+Called through the C ABI and compared with rt_run_device on the same inputs: identical bits, on two calls in a row,
+the second with a smaller input (the array keeps the first call's contents), and once more after a larger one."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _tables(n=96):
+    wl = np.round(np.linspace(0.1, 1.0, n), 4)
+    return wl, np.linspace(0.3, 0.8, n), np.linspace(0.4, 0.95, n), np.linspace(2.0, 0.5, n), np.linspace(1.0, 0.1, n) / n
+
+
+def _run(rt, eng, torch, tau, n_photons, static, n_depth_bins=0, **kw):
+    A = rt._abi
+    prm = rt.make_params(tau, n_photons, n_mu_bins=10, n_depth_bins=n_depth_bins, **kw)
+    na, ns = prm.n_atm, 8
+    dev = torch.device("cuda", 0)
+    # buffers start as garbage: the entry point must clear what has to start at zero
+    slab = torch.full((na * ns * A.NSUM,), 7.0, dtype=torch.float64, device=dev)
+    counts = torch.full((na * A.NCNT,), 7, dtype=torch.int64, device=dev)
+    hist = torch.full((na * 11,), 7, dtype=torch.int64, device=dev)
+    depth = torch.full((max(2 * na * n_depth_bins, 1),), 7.0, dtype=torch.float64, device=dev)
+    eng.run_device(prm, slab.data_ptr(), counts.data_ptr(), hist.data_ptr(), depth.data_ptr() if n_depth_bins else None,
+                   torch.cuda.current_stream().cuda_stream, static=static)
+    torch.cuda.synchronize()
+    return slab.cpu().numpy(), counts.cpu().numpy(), hist.cpu().numpy(), depth.cpu().numpy()
+
+
+def test_static_entry_point_matches_the_allocating_one(rt):
+    import torch
+    eng = rt.Engine(0)
+    eng.set_tables(*_tables())
+    big = (np.logspace(-2, 1.5, 24), 400000)
+    small = (np.array([0.2, 3.0, 30.0]), 5003)          # fewer atmospheres, fewer and ragged chunks
+    want = {k: _run(rt, eng, torch, *v, static=False) for k, v in (("big", big), ("small", small))}
+    for name in ("big", "small", "big", "small", "small"):  # back to back: the array holds the previous call's data
+        got = _run(rt, eng, torch, *(big if name == "big" else small), static=True)
+        for g, w in zip(got[:3], want[name][:3]):
+            assert np.array_equal(g, w), name
+    assert int(want["small"][1].reshape(-1, 10)[:, rt._abi.CNT_PHOTONS].sum()) == 3 * 5003
+    # other kernels and options go through the same work memory: generic kernel with depth bins, a rank's share
+    for kw in (dict(boundary="absorb", n_depth_bins=8), dict(rank=1, world=4), dict(order="gray", h=1.0)):
+        a = _run(rt, eng, torch, *small, static=False, **kw)
+        b = _run(rt, eng, torch, *small, static=True, **kw)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+        if kw.get("n_depth_bins"):
+            np.testing.assert_allclose(b[3], a[3], rtol=1e-12)   # floating-point atomics: equal to rounding
+    eng.close()
+
+
+def test_static_entry_point_refuses_what_does_not_fit(rt):
+    import torch
+    eng = rt.Engine(0)
+    eng.set_tables(*_tables())
+    with pytest.raises(rt.RtError, match="at most 4096 atmospheres"):
+        _run(rt, eng, torch, np.full(4097, 1.0), 10, static=True)
+    with pytest.raises(rt.RtError, match="work memory"):
+        _run(rt, eng, torch, np.full(100, 1.0), 2 * 10 ** 9, static=True)      # 12 million chunks
+    # nothing was enqueued by the refused calls; the next one is unaffected
+    a = _run(rt, eng, torch, np.array([1.0]), 1000, static=True)
+    b = _run(rt, eng, torch, np.array([1.0]), 1000, static=False)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    eng.close()
