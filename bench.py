@@ -282,10 +282,7 @@ def main():
     events_last = int(last[:, A.CNT_SCATTER].sum())
     events_rank_last = events_last / world  # equal shares by construction
 
-    fast = (cfg["boundary"], cfg["scatter"], cfg["order"]) == ("reflect", "hg", "mc")  # the kernel rt_run picks
-    packed = args.rng == "philox32x4"
-    plain = fast and not packed and not cfg["monochromatic"]  # no workload sets rand_mu
-    kernel_name = "walk_kernel<%s, %s, %s>" % tuple("true" if b else "false" for b in (fast, packed, plain))
+    kernel_name = eng.last_kernel()  # the instantiation the library picked for these flags
     if rank == 0:
         value = events / dt
         achieved = events_rank_last * FP64_OPS_PER_EVENT / (kernel_ms * 1e-3) / 1e12

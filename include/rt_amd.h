@@ -356,6 +356,10 @@ int rt_selftest_math(rt_ctx* ctx, int64_t n, const double* u, double* out_log, d
  * measured with HIP events on the stream the kernel ran on. */
 int rt_kernel_time(rt_ctx* ctx, double* avg_ms, int64_t* launches, int reset);
 
+/* Name of the walk-kernel instantiation that served the context's last sweep ("" before the first): the sweep's
+ * flags decide whether a kernel with those flags fixed at compile time or the one that reads them at run time runs. */
+const char* rt_last_kernel(rt_ctx* ctx);
+
 #ifdef __cplusplus
 }
 #endif

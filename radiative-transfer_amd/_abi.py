@@ -97,7 +97,7 @@ class RtPhotonTrace(C.Structure):
 
 EXPORTS = ["rt_abi_version", "rt_last_error", "rt_create", "rt_destroy", "rt_device_info", "rt_set_tables",
            "rt_run", "rt_run_device", "rt_replay", "rt_kernel_time", "rt_selftest_math", "rt_build_grain_tables",
-           "rt_shell_velocity", "rt_shell_rhs", "rt_set_tables_multi", "rt_run_device_static"]
+           "rt_shell_velocity", "rt_shell_rhs", "rt_set_tables_multi", "rt_run_device_static", "rt_last_kernel"]
 
 _lib = None
 
@@ -115,6 +115,8 @@ def load_library(path=None):
     vp = C.c_void_p
     lib.rt_abi_version.restype = C.c_int
     lib.rt_last_error.restype = C.c_char_p
+    lib.rt_last_kernel.restype = C.c_char_p
+    lib.rt_last_kernel.argtypes = [vp]
     lib.rt_create.argtypes = [C.POINTER(vp), C.c_int]
     lib.rt_destroy.argtypes = [vp]
     lib.rt_device_info.argtypes = [vp, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
@@ -136,7 +138,7 @@ def load_library(path=None):
     lib.rt_kernel_time.argtypes = [vp, c_double_p, C.POINTER(C.c_int64), C.c_int]
     for name in EXPORTS:
         getattr(lib, name)  # AttributeError if an entry point is missing
-        if name != "rt_last_error":
+        if name not in ("rt_last_error", "rt_last_kernel"):
             getattr(lib, name).restype = C.c_int
     if lib.rt_abi_version() != RT_ABI_VERSION:
         raise OSError(f"{path}: ABI version {lib.rt_abi_version()} != {RT_ABI_VERSION}")

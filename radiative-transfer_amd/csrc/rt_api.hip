@@ -94,8 +94,9 @@ struct rt_ctx {
     // result staging for rt_run / rt_replay
     DevBuf<double> d_slab_sums, d_depth, d_sums;
     DevBuf<unsigned long long> d_counts, d_mu_hist;
-    int blocks_per_cu[5] = {0, 0, 0, 0, 0};  // occupancy of walk_kernel<fast, packed, false> ([4]: <true, false, true>) for blocks_lds bytes of LDS
-    size_t blocks_lds[5] = {0, 0, 0, 0, 0};
+    int blocks_per_cu[rt::kWalkVariants] = {};  // occupancy of each walk-kernel variant for blocks_lds bytes of LDS
+    size_t blocks_lds[rt::kWalkVariants] = {};
+    int last_variant = -1;  // the variant the last sweep ran (rt_last_kernel)
     // kernel timing
     std::vector<EventPair> events;
     size_t events_used = 0;
@@ -216,6 +217,27 @@ void drain_events(rt_ctx* ctx) {
     ctx->events_used = 0;
 }
 
+
+// Which instantiation of the walk kernel serves a sweep: one with the sweep's flags fixed at compile time where there
+// is one, else the kernel that reads every flag at run time.
+rt::WalkVariant pick_variant(const rt_params* p, const rt::Cfg& cfg) {
+    const bool packed = p->rng_mode == RT_RNG_PHILOX32X4;
+    const bool slab = p->geometry == RT_GEOM_SLAB && !p->abs_only;
+    const bool mc = p->loop_order == RT_ORDER_MC, reflect = p->boundary == RT_BOUNDARY_REFLECT, hg = p->scatter == RT_SCATTER_HG;
+    const bool depth = p->n_depth_bins > 0;
+    if (slab && mc && reflect && hg && !depth) {
+        if (packed) return rt::kWalkBasePacked;
+        return (!p->rand_mu && cfg.mono_index < 0) ? rt::kWalkPlain : rt::kWalkBase;  // the reference's defaults throughout
+    }
+    if (slab && !packed) {
+        if (mc && reflect && hg && depth) return rt::kWalkDepth;
+        if (mc && hg && !depth && p->boundary == RT_BOUNDARY_ABSORB) return rt::kWalkAbsorb;
+        if (mc && hg && !depth && p->boundary == RT_BOUNDARY_REEMIT) return rt::kWalkReemit;
+        if (mc && reflect && !depth && p->scatter == RT_SCATTER_ISO) return rt::kWalkIso;
+        if (!mc && reflect && hg && !depth) return rt::kWalkGray;
+    }
+    return packed ? rt::kWalkRuntimePacked : rt::kWalkRuntime;
+}
 
 // Device work memory of one sweep, one block of bytes:
 //   [plan: n_atm PlanEntry][item prefix: n_atm + 1 u32]           uploaded with one copy
@@ -364,18 +386,14 @@ int enqueue_sweep(rt_ctx* ctx, const rt_params* p, void* d_slab_sums, void* d_co
     sw.owned_slabs = owned;
     sw.n_copies = lay.n_copies;
 
-    const bool fast = p->loop_order == RT_ORDER_MC && p->boundary == RT_BOUNDARY_REFLECT &&
-                      p->scatter == RT_SCATTER_HG && p->n_depth_bins == 0 && !p->abs_only &&
-                      p->geometry == RT_GEOM_SLAB;
-    const size_t lds = rt::walk_lds_bytes(cfg.n_mu_bins, fast ? 0 : cfg.n_depth_bins);  // within the limit: check_common
-    const bool packed = p->rng_mode == RT_RNG_PHILOX32X4;
-    const bool plain = fast && !packed && !p->rand_mu && cfg.mono_index < 0;  // the reference's defaults throughout
-    const int variant = plain ? 4 : (fast ? 1 : 0) + (packed ? 2 : 0);
+    const rt::WalkVariant variant = pick_variant(p, cfg);
+    const size_t lds = rt::walk_lds_bytes(cfg.n_mu_bins, rt::walk_variant_has_depth(variant) ? cfg.n_depth_bins : 0);  // within the limit: check_common
     int& cached = ctx->blocks_per_cu[variant];
     if (cached <= 0 || ctx->blocks_lds[variant] != lds) {
-        cached = rt::walk_max_blocks_per_cu(fast, packed, plain, lds);
+        cached = rt::walk_max_blocks_per_cu(variant, lds);
         ctx->blocks_lds[variant] = lds;
     }
+    ctx->last_variant = variant;
     const int per_cu = cached;
     long long grid = (long long)ctx->prop.multiProcessorCount * per_cu;
     const long long need = ((long long)items + 3) / 4;
@@ -404,7 +422,7 @@ int enqueue_sweep(rt_ctx* ctx, const rt_params* p, void* d_slab_sums, void* d_co
         RT_HIP(next_events(ctx, &ev));
         RT_HIP(hipEventRecord(ev->a, stream));
     }
-    RT_HIP(rt::launch_walk(cfg, sw, fast, packed, plain, (int)grid, stream, d_next, d_chunk_sums, d_count_copies,
+    RT_HIP(rt::launch_walk(cfg, sw, variant, (int)grid, stream, d_next, d_chunk_sums, d_count_copies,
                            d_hist_copies, (double*)d_depth));
     if (ev) RT_HIP(hipEventRecord(ev->b, stream));
     RT_HIP(rt::launch_slab_reduce(sw, d_chunk_sums, (double*)d_slab_sums, stream));
@@ -990,6 +1008,11 @@ int rt_selftest_math(rt_ctx* ctx, int64_t n, const double* u, double* out_log, d
     d.release();
     if (e != hipSuccess) return fail(RT_ERR_DEVICE, "selftest failed: %s", hipGetErrorString(e));
     return RT_OK;
+}
+
+const char* rt_last_kernel(rt_ctx* ctx) {
+    if (!ctx || ctx->last_variant < 0) return "";
+    return rt::walk_variant_name((rt::WalkVariant)ctx->last_variant);
 }
 
 int rt_kernel_time(rt_ctx* ctx, double* avg_ms, int64_t* launches, int reset) {

@@ -123,6 +123,35 @@ struct Cfg {
     const LogTableEntry* log_table;  // kLogTableEntries entries in global memory (copied to LDS per workgroup)
 };
 
+// Which run flags a kernel has fixed at compile time.  Fixed<...>: loop order, lower boundary, scattering law and the
+// depth tally are template constants (abs_only off, slab geometry), so the code of every other option is not in
+// the kernel at all; Runtime: everything is read from cfg.
+template <int ORDER, int BOUNDARY, int LAW, bool DEPTH>
+struct Fixed {
+    static constexpr bool kFixed = true;
+    static constexpr bool kDepth = DEPTH;
+    static constexpr bool kReemit = BOUNDARY == RT_BOUNDARY_REEMIT;
+    static __device__ __forceinline__ bool gray(const Cfg&) { return ORDER == RT_ORDER_GRAY; }
+    static __device__ __forceinline__ int boundary(const Cfg&) { return BOUNDARY; }
+    static __device__ __forceinline__ int law(const Cfg&) { return LAW; }
+    static __device__ __forceinline__ bool depth(const Cfg&) { return DEPTH; }
+    static __device__ __forceinline__ bool abs_only(const Cfg&) { return false; }
+    static __device__ __forceinline__ bool shell(const Cfg&) { return false; }
+};
+struct Runtime {
+    static constexpr bool kFixed = false;
+    static constexpr bool kDepth = true;
+    static constexpr bool kReemit = true;
+    static __device__ __forceinline__ bool gray(const Cfg& c) { return c.order == RT_ORDER_GRAY; }
+    static __device__ __forceinline__ int boundary(const Cfg& c) { return c.boundary; }
+    static __device__ __forceinline__ int law(const Cfg& c) { return c.scatter; }
+    static __device__ __forceinline__ bool depth(const Cfg& c) { return c.n_depth_bins > 0; }
+    static __device__ __forceinline__ bool abs_only(const Cfg& c) { return c.abs_only != 0; }
+    static __device__ __forceinline__ bool shell(const Cfg& c) { return c.geometry == RT_GEOM_SHELL; }
+};
+// the reference's production configuration (MC code.py: reflecting floor, Henyey-Greenstein, two escape tests)
+typedef Fixed<RT_ORDER_MC, RT_BOUNDARY_REFLECT, RT_SCATTER_HG, false> FixedBase;
+
 struct Photon {
     double z, mu, wh, g, albedo, zmax, inv2g, opg2, omg2, p0, e1, b;
     double dep;  // RT_GEOM_SHELL: radial momentum this photon has deposited so far
@@ -150,15 +179,17 @@ struct Acc {
 // 16 fewer vector registers and 10 fewer vector instructions per iteration, no change in run time.)
 struct AccWave {
     double s[RT_NSUM];
-    uint32_t hits;
+    uint32_t hits, reemits;  // per lane: a photon can meet the boundary any number of times
     __device__ __forceinline__ void clear() {
 #pragma unroll
         for (int k = 0; k < RT_NSUM; ++k) s[k] = 0.0;
         hits = 0u;
+        reemits = 0u;
     }
     __device__ __forceinline__ void add(int k, double v) { s[k] += v; }
     __device__ __forceinline__ void count(int k) {
         if (k == RT_CNT_BOUNDARY_HITS) hits++;
+        if (k == RT_CNT_REEMITTED) reemits++;
     }
     __device__ __forceinline__ void count_if(int, bool) {}
 };
@@ -274,10 +305,10 @@ __device__ __forceinline__ TableRec load_record(const Cfg& cfg, int i) {
 }
 
 // `local` is the record's index inside its table (the wavelength index).
-template <bool FAST>
+template <class V>
 __device__ __forceinline__ void set_constants(const Cfg& cfg, double tau, const TableRec& r, int local, double mu0,
                                               Photon& ph) {
-    const double w = (!FAST && cfg.order == RT_ORDER_GRAY) ? cfg.lam[local] : r.inv_lam;
+    const double w = V::gray(cfg) ? cfg.lam[local] : r.inv_lam;
     ph.wh = w * cfg.h;
     ph.g = r.g;
     ph.albedo = r.albedo;
@@ -296,11 +327,13 @@ __device__ __forceinline__ void emit_from_table(const Cfg& cfg, double tau, Phil
     src.emit_pair(ua, ub);
     const int i = sample_index(cfg, ua);
     const TableRec r = load_record(cfg, i);
-    set_constants<false>(cfg, tau, r, i - cfg.table_base, cfg.rand_mu ? ub : 1.0, ph);
+    set_constants<Runtime>(cfg, tau, r, i - cfg.table_base, cfg.rand_mu ? ub : 1.0, ph);
 }
 
+// LEAN: the quotient by the unscaled division sequence (the IEEE quotient for the normal operands that occur: 0 <= z <= zmax)
+template <bool LEAN = false>
 __device__ __forceinline__ int depth_bin(const Cfg& cfg, const Photon& ph) {
-    int k = (int)floor((double)cfg.n_depth_bins * (ph.z / ph.zmax));
+    int k = (int)floor((double)cfg.n_depth_bins * (LEAN ? div_unit(ph.z, ph.zmax) : ph.z / ph.zmax));
     k = k < 0 ? 0 : k;
     return k >= cfg.n_depth_bins ? cfg.n_depth_bins - 1 : k;
 }
@@ -374,18 +407,17 @@ __device__ __forceinline__ int fly_shell(const Cfg& cfg, Photon& ph, double path
 //              RT_FATE_* if its history ends here, 0 if it goes on to scatter.
 //   scatter()  HGScatter / IsoScatter / Draine sampling + RotateIntoLabFrame.  Returns 0, or
 //              RT_FATE_GUARD when a bounded stream runs out.
-// FAST fixes (RT_ORDER_MC, reflect, hg, no depth bins, abs_only off) at compile time; the
-// generic form reads cfg.  `reemit` is called when a photon is re-emitted at the lower boundary.
+// V (Fixed<...> or Runtime) says which flags are compile-time constants; the generic form reads cfg.  `reemit` is called when a photon is re-emitted at the lower boundary.
 // ---------------------------------------------------------------------------
 // fly() with the optical length of the step, -ln(xi), already formed (a caller that has independent memory
 // requests in flight takes the logarithm first, so that it runs under their latency).
-template <bool FAST, class Reemit, class AccT>
+template <class V, class Reemit, class AccT>
 __device__ __forceinline__ int fly_path(const Cfg& cfg, Photon& ph, double path, double u_abs, int avail, bool bounded,
                                         AccT& acc, const Hist& hist, Reemit&& reemit, int& n_used) {
-    const bool gray = FAST ? false : cfg.order == RT_ORDER_GRAY;
-    const int boundary = FAST ? (int)RT_BOUNDARY_REFLECT : cfg.boundary;
-    const bool depth = FAST ? false : cfg.n_depth_bins > 0;
-    const bool shell = FAST ? false : cfg.geometry == RT_GEOM_SHELL;
+    const bool gray = V::gray(cfg);
+    const int boundary = V::boundary(cfg);
+    const bool depth = V::depth(cfg);
+    const bool shell = V::shell(cfg);
 
     if (bounded && avail < 1) return RT_FATE_GUARD;
     ph.iter++;
@@ -433,14 +465,14 @@ __device__ __forceinline__ int fly_path(const Cfg& cfg, Photon& ph, double path,
     // Absorb
     if (bounded && avail < 2) return RT_FATE_GUARD;
     n_used += 1;
-    const bool absorbed = (!FAST && cfg.abs_only) ? (u_abs > 0.0) : (u_abs > ph.albedo);
+    const bool absorbed = V::abs_only(cfg) ? (u_abs > 0.0) : (u_abs > ph.albedo);
     if (absorbed) {
         const double pa = ph.mu * ph.wh;
         acc.add(RT_SUM_DUST_MOMENTUM, pa);
         acc.add(RT_SUM_ABSORBED_ENERGY, ph.wh);
         if (shell) ph.dep += pa;
         if (depth) {
-            const int k = depth_bin(cfg, ph);
+            const int k = depth_bin<V::kFixed>(cfg, ph);
             atomicAdd(&hist.depth_mom[k], pa);
             atomicAdd(&hist.depth_en[k], ph.wh);
         }
@@ -449,30 +481,31 @@ __device__ __forceinline__ int fly_path(const Cfg& cfg, Photon& ph, double path,
     return 0;
 }
 
-template <bool FAST, class Reemit, class AccT>
+template <class V, class Reemit, class AccT>
 __device__ __forceinline__ int fly(const Cfg& cfg, Photon& ph, double u_step, double u_abs, int avail, bool bounded,
                                    AccT& acc, const Hist& hist, Reemit&& reemit, int& n_used) {
     if (bounded && avail < 1) return RT_FATE_GUARD;  // before the logarithm: its argument is not a draw then
     const double path = -log_unit(u_step, hist.log_table);
-    return fly_path<FAST>(cfg, ph, path, u_abs, avail, bounded, acc, hist, reemit, n_used);
+    return fly_path<V>(cfg, ph, path, u_abs, avail, bounded, acc, hist, reemit, n_used);
 }
 
 // LEAN (the production walk kernel): the cosine's polynomial coefficients are read from LDS (hist.coef), and 1 + g^2 and
 // 1 - g^2 are formed here from g (the same two operations set_constants performs, so the same values) instead
 // of being carried in ph: fewer registers held across the loop, same results.
 // MFORM: u_phi is passed as m = 1 + u (see m52).
-template <bool FAST, bool LEAN = false, bool MFORM = false, class Src, class AccT>
+template <class V, bool LEAN = false, bool MFORM = false, class Src, class AccT>
 __device__ __forceinline__ int scatter(const Cfg& cfg, Photon& ph, Src& src, double u_phi, double u_s, int avail2,
                                        AccT& acc, const Hist& hist) {
-    const bool gray = FAST ? false : cfg.order == RT_ORDER_GRAY;
-    const int law = FAST ? (int)RT_SCATTER_HG : cfg.scatter;
-    const bool depth = FAST ? false : cfg.n_depth_bins > 0;
-    const bool shell = FAST ? false : cfg.geometry == RT_GEOM_SHELL;
+    constexpr bool FAST = V::kFixed;  // unscaled division / square root, one rotation formula
+    const bool gray = V::gray(cfg);
+    const int law = V::law(cfg);
+    const bool depth = V::depth(cfg);
+    const bool shell = V::shell(cfg);
     if (Src::kBounded && avail2 < 2) return RT_FATE_GUARD;
     src.used(2);
     const double mu_old = ph.mu;
     bool iso = false;
-    if (!FAST) {
+    {
         if (law == RT_SCATTER_ISO) iso = gray ? true : (ph.iter == 1u);
         if (gray && law == RT_SCATTER_HG && ph.g == 0.0) iso = true;
         // the gray script's Draine branch falls back to IsoScatter for g == 0 and alpha == 0 (Numpy_random_walk.py:388-391)
@@ -480,7 +513,7 @@ __device__ __forceinline__ int scatter(const Cfg& cfg, Photon& ph, Src& src, dou
     }
     double mu_prime;
     bool direct = false;
-    if (!FAST && (law == RT_SCATTER_DRAINE || law == RT_SCATTER_DRAINE_EXACT) && !iso) {
+    if ((law == RT_SCATTER_DRAINE || law == RT_SCATTER_DRAINE_EXACT) && !iso) {
         mu_prime = 0.0;
         bool ok = false;
         // rejection sampling of the Draine phase function, one pair (y, candidate) per try.  The bound only ends
@@ -531,6 +564,7 @@ __device__ __forceinline__ int scatter(const Cfg& cfg, Photon& ph, Src& src, dou
         // there: 1 - mu^2 is exactly 0, so the first term is -(+-0) and the sum is mu' or -mu' exactly.
         const double c = LEAN ? cos_2pi<MFORM>(u_phi, hist.coef) : cos_2pi(u_phi);
         mu_new = -sqrt_unit((1.0 - mu_old * mu_old) * (1.0 - mu_prime * mu_prime)) * c + mu_old * mu_prime;
+        if (direct) mu_new = mu_prime;  // IsoScatter assigns the lab-frame cosine itself (MC code.py:741-743)
     } else if (direct || mu_old == 1.0) {
         mu_new = mu_prime;
     } else if (mu_old == -1.0) {
@@ -544,34 +578,34 @@ __device__ __forceinline__ int scatter(const Cfg& cfg, Photon& ph, Src& src, dou
     const double dp = (mu_old - mu_new) * ph.wh;
     acc.add(RT_SUM_DUST_MOMENTUM, dp);
     if (shell) ph.dep += dp;
-    if (depth) atomicAdd(&hist.depth_mom[depth_bin(cfg, ph)], dp);
+    if (depth) atomicAdd(&hist.depth_mom[depth_bin<V::kFixed>(cfg, ph)], dp);
     return 0;
 }
 
 // fly() then scatter() with the stream's own pairs: the generic kernel and the replay kernel.
-template <bool FAST, class Src, class Reemit>
+template <class V, class Src, class Reemit>
 __device__ __forceinline__ int flight(const Cfg& cfg, Photon& ph, Src& src, Acc& acc, const Hist& hist,
                                       Reemit&& reemit) {
     if (ph.iter >= (uint32_t)cfg.max_events) return RT_FATE_GUARD;
     double u_step, u_abs;
     const int avail = src.pair(u_step, u_abs);
     int n_used = 0;
-    const int fate = fly<FAST>(cfg, ph, u_step, u_abs, avail, Src::kBounded, acc, hist, reemit, n_used);
+    const int fate = fly<V>(cfg, ph, u_step, u_abs, avail, Src::kBounded, acc, hist, reemit, n_used);
     src.used(n_used);
     if (fate != 0) return fate;
     double u_phi, u_s;
     const int avail2 = src.pair(u_phi, u_s);
-    return scatter<FAST>(cfg, ph, src, u_phi, u_s, avail2, acc, hist);
+    return scatter<V>(cfg, ph, src, u_phi, u_s, avail2, acc, hist);
 }
 
 // Bookkeeping when a photon's history ends.
 // UNIT_MU0: every photon starts with mu = 1, so its initial momentum p0 = 1 * wh is wh itself and ph.p0 need not
 // be kept.
-template <bool UNIT_MU0 = false, class AccT>
-__device__ __forceinline__ void retire(const Cfg& cfg, const Photon& ph, int fate, AccT& acc, const Hist& hist,
-                                       bool shell = false) {
+template <bool UNIT_MU0 = false, class V = Runtime, class AccT>
+__device__ __forceinline__ void retire(const Cfg& cfg, const Photon& ph, int fate, AccT& acc, const Hist& hist) {
     const double p0 = UNIT_MU0 ? ph.wh : ph.p0;
-    const bool gray = cfg.order == RT_ORDER_GRAY || shell;  // a shell has one escape test: every escape is logged
+    const bool shell = V::shell(cfg);
+    const bool gray = V::gray(cfg) || shell;  // a shell has one escape test: every escape is logged
     acc.count_if(RT_CNT_ESCAPED, fate == RT_FATE_ESCAPED);
     acc.count_if(RT_CNT_ESCAPED_UNCOUNTED, fate == RT_FATE_ESCAPED_UNCOUNTED);
     acc.count_if(RT_CNT_ABSORBED, fate == RT_FATE_ABSORBED);

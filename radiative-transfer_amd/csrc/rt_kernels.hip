@@ -177,8 +177,9 @@ __device__ __forceinline__ void store_chunk(const Acc& acc, const WorkItem& it, 
 }
 
 // Same for the fast kernel: the integer tallies are already wave totals (wave-uniform values).
+template <bool REEMITS>
 __device__ __forceinline__ void store_chunk_wave(const AccWave& acc, const unsigned long long (&wc)[RT_NCNT],
-                                                 const WorkItem& it, const Hist& hist, int lane, int nmu,
+                                                 const WorkItem& it, const Hist& hist, int lane, int nmu, int nd,
                                                  uint32_t n_atm, double* d_chunk_sums, unsigned long long* d_counts,
                                                  unsigned long long* d_mu_hist, double* d_depth) {
 #pragma unroll
@@ -187,12 +188,15 @@ __device__ __forceinline__ void store_chunk_wave(const AccWave& acc, const unsig
         if (lane == 0) d_chunk_sums[it.slot * RT_NSUM + k] = v;
     }
     const uint32_t hits = wave_sum_u32(acc.hits);
+    const uint32_t reemits = REEMITS ? wave_sum_u32(acc.reemits) : 0u;
 #pragma unroll
     for (int k = 0; k < RT_NCNT; ++k) {
-        const unsigned long long v = k == RT_CNT_BOUNDARY_HITS ? (unsigned long long)hits : wc[k];
+        const unsigned long long v = k == RT_CNT_BOUNDARY_HITS ? (unsigned long long)hits
+                                     : k == RT_CNT_REEMITTED   ? (unsigned long long)reemits
+                                                               : wc[k];
         if (lane == 0 && v) atomicAdd(&d_counts[(size_t)it.atm * RT_NCNT + k], v);
     }
-    flush_hist(hist, lane, nmu, 0, it.atm, n_atm, d_mu_hist, d_depth);
+    flush_hist(hist, lane, nmu, nd, it.atm, n_atm, d_mu_hist, d_depth);
 }
 
 // The persistent walk kernel.  The loop is rotated so that the two lane populations that exist after a
@@ -201,13 +205,14 @@ __device__ __forceinline__ void store_chunk_wave(const AccWave& acc, const unsig
 // photon id, or the scattering block of the current one) and the 128 output bits are then read
 // as the emission draws or as (azimuth, cosine).  The alias-table entry of the new photons is
 // requested before the scattering arithmetic runs, so the first gather's latency hides under it.
-//   FAST = true   the reference's production configuration fixed at compile time: RT_ORDER_MC, reflecting
-//                 boundary, Henyey-Greenstein, no depth bins, abs_only off; integer tallies per wave.
-//   FAST = false  every boundary / scattering law / loop order, depth bins, re-emission, read from cfg.
+//   V = Fixed<order, boundary, law, depth>  these flags fixed at compile time (abs_only off, slab geometry): the lean
+//                 loop with integer tallies per wave.  FixedBase is the reference's production configuration
+//                 (RT_ORDER_MC, reflecting boundary, Henyey-Greenstein, no depth bins).
+//   V = Runtime   every boundary / scattering law / loop order, depth bins, abs_only, shell geometry, read from cfg.
 // Both give the same photon histories as one fly() + scatter() per photon per iteration (flight()).
 //   PLAIN (with FAST) also fixes the reference's defaults rand_mu = 0 and monochromatic = 0 at compile time: the
 //                 selects they cost per emission, and the scalar registers their operands occupy, go away.
-template <bool FAST, bool PACKED, bool PLAIN>
+template <class V, bool PACKED, bool PLAIN>
 __global__ __launch_bounds__(kWalkBlock) void walk_kernel(const Cfg cfg0, const Sweep sw,
                                                            unsigned int* __restrict__ d_next,
                                                            double* __restrict__ d_chunk_sums,
@@ -219,14 +224,15 @@ __global__ __launch_bounds__(kWalkBlock) void walk_kernel(const Cfg cfg0, const 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int nmu = cfg0.n_mu_bins + 1;
-    const int nd = FAST ? 0 : cfg0.n_depth_bins;
+    constexpr bool FAST = V::kFixed;  // lean loop: wave-level integer tallies, scalar lane bookkeeping, buffer loads
+    const int nd = V::kDepth ? cfg0.n_depth_bins : 0;
     const Hist hist = wave_hist(lds_raw, wave, nmu, nd);
     stage_log_table(cfg0, lds_raw);
     clear_hist(hist, lane, nmu, nd);
     // Integer tallies and the escape histogram go to one of n_copies copies of the tally arrays (folded afterwards):
     // with one copy, all the waves that finish chunks of the same atmosphere queue up on the same few cache lines.
     {
-        const uint32_t copy = ((uint32_t)blockIdx.x * kWavesPerBlock + (uint32_t)wave) % sw.n_copies;
+        const uint32_t copy = __builtin_amdgcn_readfirstlane(((uint32_t)blockIdx.x * kWavesPerBlock + (uint32_t)wave) % sw.n_copies);
         d_counts += (size_t)copy * sw.n_atm * RT_NCNT;
         d_mu_hist += (size_t)copy * sw.n_atm * (size_t)nmu;
     }
@@ -248,7 +254,7 @@ __global__ __launch_bounds__(kWalkBlock) void walk_kernel(const Cfg cfg0, const 
         acc.clear();
         // FAST: wave totals in scalar registers.  A chunk has at most 16384 photons, so everything that happens
         // once per photon fits 32 bits; scatterings do not (up to max_events per photon).
-        uint32_t n_photons = 0u, n_escaped = 0u, n_uncounted = 0u, n_guarded = 0u;
+        uint32_t n_photons = 0u, n_escaped = 0u, n_uncounted = 0u, n_guarded = 0u, n_floor = 0u;
         unsigned long long n_scatter = 0ull;
         Photon ph = {};
         PhiloxSrc src = {};
@@ -259,7 +265,7 @@ __global__ __launch_bounds__(kWalkBlock) void walk_kernel(const Cfg cfg0, const 
 
         // CheckBoundary 'reemit' (MC code.py:539-547): fresh table values and direction, same history
         auto reemit = [&](Photon& p) {
-            if (!FAST) {
+            if (V::boundary(cfg) == RT_BOUNDARY_REEMIT) {
                 const double p0 = p.p0, e1 = p.e1, b = p.b;
                 const uint32_t n_it = p.iter;
                 const int ns = p.n_scatter;
@@ -334,7 +340,7 @@ __global__ __launch_bounds__(kWalkBlock) void walk_kernel(const Cfg cfg0, const 
                 int scatter_fate = 0;
                 if (!fresh) {
                     ++src.blk;
-                    scatter_fate = scatter<FAST, FAST, MFORM>(cfg, ph, src, ua, ub, 2, acc, hist);
+                    scatter_fate = scatter<V, FAST, MFORM>(cfg, ph, src, ua, ub, 2, acc, hist);
                 }
                 const double prob = __hiloint2double((int)raw.y, (int)raw.x);
                 int idx = (xb - (double)bucket) < prob ? bucket : (int)raw.z;
@@ -359,7 +365,7 @@ __global__ __launch_bounds__(kWalkBlock) void walk_kernel(const Cfg cfg0, const 
                     src.pair(u_step, u_abs);
                 }
                 if (fresh) {
-                    set_constants<FAST>(cfg, tau, rec, local, (!PLAIN && cfg.rand_mu) ? ub : 1.0, ph);
+                    set_constants<V>(cfg, tau, rec, local, (!PLAIN && cfg.rand_mu) ? ub : 1.0, ph);
                     start_photon(ph, acc);
                     alive = true;
                 }
@@ -370,10 +376,10 @@ __global__ __launch_bounds__(kWalkBlock) void walk_kernel(const Cfg cfg0, const 
                     // FAST: polynomial coefficients from LDS (5 waves per SIMD); the generic kernel is bound by its
                     // other registers (3 waves per SIMD either way) and keeps them in registers
                     const double path = FAST ? -log_unit(u_step, hist.log_table, hist.coef) : -log_unit(u_step, hist.log_table);
-                    fate = fly_path<FAST>(cfg, ph, path, u_abs, 2, false, acc, hist, reemit, n_used);
+                    fate = fly_path<V>(cfg, ph, path, u_abs, 2, false, acc, hist, reemit, n_used);
                 }
                 if (fate != 0) {
-                    retire<PLAIN>(cfg, ph, fate, acc, hist, !FAST && cfg.geometry == RT_GEOM_SHELL);
+                    retire<PLAIN, V>(cfg, ph, fate, acc, hist);
                     alive = false;
                 }
             }
@@ -381,6 +387,8 @@ __global__ __launch_bounds__(kWalkBlock) void walk_kernel(const Cfg cfg0, const 
                 n_guarded += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(fate == RT_FATE_GUARD));
                 n_escaped += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(fate == RT_FATE_ESCAPED));
                 n_uncounted += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(fate == RT_FATE_ESCAPED_UNCOUNTED));
+                if (V::boundary(cfg) == RT_BOUNDARY_ABSORB)
+                    n_floor += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(fate == RT_FATE_BOUNDARY));
                 // lanes without a photon at the top of the next iteration: those whose photon ended now (fate is 0
                 // in lanes that were not active) and the dead lanes that got no new one (only when the chunk runs out)
                 dead = __builtin_amdgcn_ballot_w64(fate != 0) | idle;
@@ -393,12 +401,13 @@ __global__ __launch_bounds__(kWalkBlock) void walk_kernel(const Cfg cfg0, const 
             wc[RT_CNT_ESCAPED] = n_escaped;
             wc[RT_CNT_ESCAPED_UNCOUNTED] = n_uncounted;
             wc[RT_CNT_GUARD] = n_guarded;
+            wc[RT_CNT_BOUNDARY_ABSORBED] = n_floor;
             // one flight per photon started and per scattering, except where the iteration guard ended the photon
             // after its scattering (fly_path itself never returns RT_FATE_GUARD for an unbounded stream)
             wc[RT_CNT_FLIGHTS] = n_scatter + n_photons - n_guarded;
             // every photon started in this chunk also ended in it
-            wc[RT_CNT_ABSORBED] = wc[RT_CNT_PHOTONS] - wc[RT_CNT_ESCAPED] - wc[RT_CNT_ESCAPED_UNCOUNTED] - wc[RT_CNT_GUARD];
-            store_chunk_wave(acc, wc, it, hist, lane, nmu, sw.n_atm, d_chunk_sums, d_counts, d_mu_hist, d_depth);
+            wc[RT_CNT_ABSORBED] = wc[RT_CNT_PHOTONS] - wc[RT_CNT_ESCAPED] - wc[RT_CNT_ESCAPED_UNCOUNTED] - wc[RT_CNT_GUARD] - n_floor;
+            store_chunk_wave<V::kReemit>(acc, wc, it, hist, lane, nmu, nd, sw.n_atm, d_chunk_sums, d_counts, d_mu_hist, d_depth);
         } else {
             store_chunk(acc, it, hist, lane, nmu, nd, sw.n_atm, d_chunk_sums, d_counts, d_mu_hist, d_depth);
         }
@@ -500,7 +509,7 @@ __global__ __launch_bounds__(kWalkBlock) void replay_kernel(const Cfg cfg, const
             p.mu = mu0[i];
         };
         int fate = 0;
-        while (fate == 0) fate = flight<false>(cfg, ph, src, acc, hist, reemit);
+        while (fate == 0) fate = flight<Runtime>(cfg, ph, src, acc, hist, reemit);
         retire(cfg, ph, fate, acc, hist);
         if (trace) {
             rt_photon_trace t;
@@ -648,32 +657,57 @@ size_t walk_lds_bytes(int n_mu_bins, int n_depth_bins) {
            sizeof(uint32_t) * kWavesPerBlock * (size_t)(n_mu_bins + 1);
 }
 
-int walk_max_blocks_per_cu(bool fast, bool packed, bool plain, size_t lds_bytes) {
+// The instantiations.  A sweep whose flags match none of the fixed ones runs the Runtime kernel.
+typedef Fixed<RT_ORDER_MC, RT_BOUNDARY_REFLECT, RT_SCATTER_HG, true> FixedDepth;
+typedef Fixed<RT_ORDER_MC, RT_BOUNDARY_ABSORB, RT_SCATTER_HG, false> FixedAbsorb;
+typedef Fixed<RT_ORDER_MC, RT_BOUNDARY_REEMIT, RT_SCATTER_HG, false> FixedReemit;
+typedef Fixed<RT_ORDER_MC, RT_BOUNDARY_REFLECT, RT_SCATTER_ISO, false> FixedIso;
+typedef Fixed<RT_ORDER_GRAY, RT_BOUNDARY_REFLECT, RT_SCATTER_HG, false> FixedGray;
+
+typedef void (*WalkKernel)(const Cfg, const Sweep, unsigned int*, double*, unsigned long long*, unsigned long long*, double*);
+
+static WalkKernel walk_kernel_of(WalkVariant v) {
+    switch (v) {
+        case kWalkPlain: return walk_kernel<FixedBase, false, true>;
+        case kWalkBase: return walk_kernel<FixedBase, false, false>;
+        case kWalkBasePacked: return walk_kernel<FixedBase, true, false>;
+        case kWalkDepth: return walk_kernel<FixedDepth, false, false>;
+        case kWalkAbsorb: return walk_kernel<FixedAbsorb, false, false>;
+        case kWalkReemit: return walk_kernel<FixedReemit, false, false>;
+        case kWalkIso: return walk_kernel<FixedIso, false, false>;
+        case kWalkGray: return walk_kernel<FixedGray, false, false>;
+        case kWalkRuntimePacked: return walk_kernel<Runtime, true, false>;
+        default: return walk_kernel<Runtime, false, false>;
+    }
+}
+
+const char* walk_variant_name(WalkVariant v) {
+    switch (v) {
+        case kWalkPlain: return "walk_kernel<FixedBase, false, true>";
+        case kWalkBase: return "walk_kernel<FixedBase, false, false>";
+        case kWalkBasePacked: return "walk_kernel<FixedBase, true, false>";
+        case kWalkDepth: return "walk_kernel<FixedDepth, false, false>";
+        case kWalkAbsorb: return "walk_kernel<FixedAbsorb, false, false>";
+        case kWalkReemit: return "walk_kernel<FixedReemit, false, false>";
+        case kWalkIso: return "walk_kernel<FixedIso, false, false>";
+        case kWalkGray: return "walk_kernel<FixedGray, false, false>";
+        case kWalkRuntimePacked: return "walk_kernel<Runtime, true, false>";
+        default: return "walk_kernel<Runtime, false, false>";
+    }
+}
+
+int walk_max_blocks_per_cu(WalkVariant v, size_t lds_bytes) {
     int nb = 0;
-    hipError_t e =
-        plain ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, walk_kernel<true, false, true>, kWalkBlock, lds_bytes)
-        : fast ? (packed ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, walk_kernel<true, true, false>, kWalkBlock, lds_bytes)
-                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, walk_kernel<true, false, false>, kWalkBlock, lds_bytes))
-               : (packed ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, walk_kernel<false, true, false>, kWalkBlock, lds_bytes)
-                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, walk_kernel<false, false, false>, kWalkBlock, lds_bytes));
+    const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, walk_kernel_of(v), kWalkBlock, lds_bytes);
     if (e != hipSuccess || nb < 1) nb = 1;
     return nb;
 }
 
-hipError_t launch_walk(const Cfg& cfg, const Sweep& sw, bool fast, bool packed, bool plain, int grid, hipStream_t stream,
+hipError_t launch_walk(const Cfg& cfg, const Sweep& sw, WalkVariant v, int grid, hipStream_t stream,
                        unsigned int* d_next, double* d_chunk_sums, unsigned long long* d_counts,
                        unsigned long long* d_mu_hist, double* d_depth) {
-    const size_t lds = walk_lds_bytes(cfg.n_mu_bins, fast ? 0 : cfg.n_depth_bins);
-    if (plain)
-        walk_kernel<true, false, true><<<grid, kWalkBlock, lds, stream>>>(cfg, sw, d_next, d_chunk_sums, d_counts, d_mu_hist, d_depth);
-    else if (fast && !packed)
-        walk_kernel<true, false, false><<<grid, kWalkBlock, lds, stream>>>(cfg, sw, d_next, d_chunk_sums, d_counts, d_mu_hist, d_depth);
-    else if (fast)
-        walk_kernel<true, true, false><<<grid, kWalkBlock, lds, stream>>>(cfg, sw, d_next, d_chunk_sums, d_counts, d_mu_hist, d_depth);
-    else if (!packed)
-        walk_kernel<false, false, false><<<grid, kWalkBlock, lds, stream>>>(cfg, sw, d_next, d_chunk_sums, d_counts, d_mu_hist, d_depth);
-    else
-        walk_kernel<false, true, false><<<grid, kWalkBlock, lds, stream>>>(cfg, sw, d_next, d_chunk_sums, d_counts, d_mu_hist, d_depth);
+    const size_t lds = walk_lds_bytes(cfg.n_mu_bins, walk_variant_has_depth(v) ? cfg.n_depth_bins : 0);
+    walk_kernel_of(v)<<<grid, kWalkBlock, lds, stream>>>(cfg, sw, d_next, d_chunk_sums, d_counts, d_mu_hist, d_depth);
     return hipGetLastError();
 }
 

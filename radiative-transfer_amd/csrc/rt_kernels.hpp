@@ -49,10 +49,25 @@ constexpr int kWalkBlock = 256;
 // entries.  The limit leaves room for several workgroups per compute unit.
 size_t walk_lds_bytes(int n_mu_bins, int n_depth_bins);
 constexpr size_t kWalkLdsLimit = 64 * 1024;
-// `plain`: fast, default random stream, rand_mu and monochromatic off (walk_kernel<true, false, true>)
-int walk_max_blocks_per_cu(bool fast, bool packed, bool plain, size_t lds_bytes);
+// The walk kernel's instantiations: which run flags are compile-time constants (see Fixed<> in rt_device.hpp).
+enum WalkVariant {
+    kWalkRuntime = 0,    // every flag read at run time
+    kWalkRuntimePacked,  // the same on the one-block random stream
+    kWalkPlain,          // production: MC order, reflect, HG, no depth bins; rand_mu and monochromatic off as well
+    kWalkBase,           // production flags; rand_mu / monochromatic read at run time
+    kWalkBasePacked,     // production flags on the one-block random stream
+    kWalkDepth,          // production flags + depth-resolved deposition
+    kWalkAbsorb,         // absorbing lower boundary
+    kWalkReemit,         // re-emitting lower boundary
+    kWalkIso,            // scatter = 'iso'
+    kWalkGray,           // the gray script's loop order
+    kWalkVariants
+};
+inline bool walk_variant_has_depth(WalkVariant v) { return v == kWalkRuntime || v == kWalkRuntimePacked || v == kWalkDepth; }
+const char* walk_variant_name(WalkVariant v);
+int walk_max_blocks_per_cu(WalkVariant v, size_t lds_bytes);
 
-hipError_t launch_walk(const Cfg& cfg, const Sweep& sw, bool fast, bool packed, bool plain, int grid, hipStream_t stream,
+hipError_t launch_walk(const Cfg& cfg, const Sweep& sw, WalkVariant v, int grid, hipStream_t stream,
                        unsigned int* d_next, double* d_chunk_sums, unsigned long long* d_counts,
                        unsigned long long* d_mu_hist, double* d_depth);  // d_counts / d_mu_hist: sw.n_copies copies each
 

@@ -223,6 +223,10 @@ class Engine:
         self._check(self._lib.rt_selftest_math(self._ctx, len(u), _dp(u), *[_dp(o) for o in outs]))
         return tuple(outs)
 
+    def last_kernel(self):
+        """Name of the walk-kernel instantiation that served the last sweep."""
+        return self._lib.rt_last_kernel(self._ctx).decode()
+
     def kernel_time(self, reset=False):
         ms, n = C.c_double(), C.c_int64()
         self._check(self._lib.rt_kernel_time(self._ctx, C.byref(ms), C.byref(n), int(reset)))

@@ -166,3 +166,20 @@ def test_device_math_accuracy(engine):
     assert np.array_equal(got[100000:], 1.0 / (2.0 * g[100000:]))
     lz, _, sz, _ = engine.selftest_math(np.array([0.0]))
     assert np.isneginf(lz[0]) and sz[0] == 0.0
+
+
+def test_which_kernel_serves_which_flags(rt, engine):
+    """Depth bins, the other boundaries, isotropic scattering and the gray loop order each have a kernel with those
+    flags fixed at compile time (the lean loop of the production kernel); only combinations without one -- abs_only,
+    the Draine laws, the shell geometry, two options at once -- run the kernel that reads every flag at run time."""
+    engine.set_tables(*small_table())
+    tau = np.array([0.5, 5.0])
+    want = [(dict(), "FixedBase, false, true"), (dict(rand_mu=1), "FixedBase, false, false"),
+            (dict(rng="philox32x4"), "FixedBase, true, false"), (dict(n_depth_bins=8), "FixedDepth"),
+            (dict(boundary="absorb"), "FixedAbsorb"), (dict(boundary="reemit"), "FixedReemit"),
+            (dict(scatter="iso"), "FixedIso"), (dict(order="gray", h=1.0), "FixedGray"),
+            (dict(abs_only=1), "Runtime, false"), (dict(boundary="absorb", n_depth_bins=8), "Runtime, false"),
+            (dict(geometry="shell", shell_inner=1.0), "Runtime, false"), (dict(scatter="iso", rng="philox32x4"), "Runtime, true")]
+    for kw, name in want:
+        engine.run(rt.make_params(tau, 2000, **kw))
+        assert name in engine.last_kernel(), (kw, engine.last_kernel())

@@ -24,5 +24,5 @@ for kw in (dict(), dict(boundary="absorb"), dict(boundary="reemit"), dict(scatte
     res = eng.run(prm)
     ms, _ = eng.kernel_time()
     ev, fl = int(res.counts[:, A.CNT_SCATTER].sum()), int(res.counts[:, A.CNT_FLIGHTS].sum())
-    print(f"{str(kw):72s} kernel {ms:8.3f} ms  flights {fl:.3e}  events {ev:.3e}  {fl / ms / 1e6:.1f} Gflights/s  {ev / ms / 1e6:.1f} Gevents/s")
+    print(f"{str(kw):72s} {eng.last_kernel()[12:-1]:28s} {ms:8.3f} ms  flights {fl:.3e}  events {ev:.3e}  {fl / ms / 1e6:.1f} Gflights/s  {ev / ms / 1e6:.1f} Gevents/s")
 eng.close()
