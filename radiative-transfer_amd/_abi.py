@@ -140,7 +140,10 @@ def load_library(path=None):
         getattr(lib, name)  # AttributeError if an entry point is missing
         if name not in ("rt_last_error", "rt_last_kernel"):
             getattr(lib, name).restype = C.c_int
-    if lib.rt_abi_version() != RT_ABI_VERSION:
-        raise OSError(f"{path}: ABI version {lib.rt_abi_version()} != {RT_ABI_VERSION}")
+    version = lib.rt_abi_version()
+    if version == (RT_ABI_VERSION | 0x1000) and os.environ.get("RT_AMD_ALLOW_ABLATION") == "1":
+        version = RT_ABI_VERSION  # a timing-experiment build (tools/ablation); its results carry no parity claim
+    if version != RT_ABI_VERSION:
+        raise OSError(f"{path}: ABI version {lib.rt_abi_version():#x} != {RT_ABI_VERSION:#x}")
     _lib = lib
     return lib

@@ -173,12 +173,7 @@ rt::Cfg make_cfg(const rt_ctx* ctx, const rt_params* p) {
 // ranks, so that the chunk partial sums -- and with them every result bit -- are the same for any number of GPUs.
 struct ChunkRule {
     uint32_t thin = 8192u, thick = 8192u;
-    ChunkRule() {
-        if (const char* e = getenv("RT_AMD_CHUNK")) {  // experiments (tools/chunk_sweep.py): "thin,thick"
-            unsigned a = 0, b = 0;
-            if (sscanf(e, "%u,%u", &a, &b) == 2 && a >= 64 && b >= 64 && a <= 65536 && b <= 65536) thin = a, thick = b;
-        }
-    }
+    ChunkRule() { (void)rt::Ablation::chunk_rule(thin, thick); }  // product builds: no-op
 };
 const ChunkRule g_chunk_rule;
 
@@ -435,7 +430,7 @@ int enqueue_sweep(rt_ctx* ctx, const rt_params* p, void* d_slab_sums, void* d_co
 
 extern "C" {
 
-int rt_abi_version(void) { return RT_ABI_VERSION; }
+int rt_abi_version(void) { return RT_ABI_VERSION | rt::Ablation::kAbiTag; }  // experiment builds are tagged
 
 const char* rt_last_error(void) { return g_last_error.c_str(); }
 

@@ -38,11 +38,8 @@ struct PhiloxOut {
 
 __device__ __forceinline__ PhiloxOut philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
                                                    uint32_t k1) {
-#ifndef RT_PHILOX_ROUNDS
-#define RT_PHILOX_ROUNDS 10  // timing experiments only; every result check assumes 10
-#endif
 #pragma unroll
-    for (int r = 0; r < RT_PHILOX_ROUNDS; ++r) {
+    for (int r = 0; r < Ablation::kPhiloxRounds; ++r) {  // 10
         const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
         const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
         // a ^ b ^ c in one instruction: v_bitop3_b32 with the truth table of three-way xor (0x96)
@@ -61,13 +58,10 @@ __device__ __forceinline__ PhiloxOut philox4x32_10(uint32_t c0, uint32_t c1, uin
 // Uniform in [0,1) with 52 random bits: the top 52 bits of a:b become the fraction of a double in [1,2),
 // minus 1 (exact).  Two funnel shifts and one subtraction; values are the multiples of 2^-52.
 __device__ __forceinline__ double u52(uint32_t a, uint32_t b) {
-#ifdef RT_UNIFORM_53
-    return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) * (1.0 / 9007199254740992.0);
-#else
+    if constexpr (Ablation::kUniform53) return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) * (1.0 / 9007199254740992.0);
     const uint32_t hi = __builtin_amdgcn_alignbit(0x3FFu, a, 12);  // 0x3FF00000 | (a >> 12)
     const uint32_t lo = __builtin_amdgcn_alignbit(a, b, 12);       // (a << 20) | (b >> 12)
     return __hiloint2double((int)hi, (int)lo) - 1.0;
-#endif
 }
 
 // The same draw before the subtraction: m = 1 + u in [1, 2).  Where a uniform only enters an affine expression

@@ -23,13 +23,15 @@ namespace rt {
 
 constexpr int kWavesPerBlock = kWalkBlock / 64;
 
-#ifdef RT_WAVE_TRACE
-// Tooling build only (tools/wave_trace.py): per wave of the last walk launch, 100 MHz clock at its first queue pop, at
-// the start of its last chunk and at its end, and the number of chunks it walked.
+#ifdef RT_ABLATION
+// Experiment builds only (tools/wave_trace.py): per wave of the last walk launch, 100 MHz clock at its first queue pop,
+// at the start of its last chunk and at its end, and the number of chunks it walked.
 __device__ unsigned long long g_wave_trace[4 * 8192];
 extern "C" int rt_debug_wave_trace(unsigned long long* out, int n_waves) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_trace), sizeof(unsigned long long) * 4 * (size_t)n_waves);
 }
+#else
+__device__ unsigned long long g_wave_trace[1];  // never written: Ablation::kWaveTrace is false
 #endif
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -237,16 +239,14 @@ __global__ __launch_bounds__(kWalkBlock) void walk_kernel(const Cfg cfg0, const 
         d_mu_hist += (size_t)copy * sw.n_atm * (size_t)nmu;
     }
 
-#ifdef RT_WAVE_TRACE
-    const unsigned long long t_begin = wall_clock64();
-    unsigned long long t_last = t_begin, n_done = 0ull;
-#endif
+    unsigned long long t_begin = 0ull, t_last = 0ull, n_done = 0ull;
+    if constexpr (Ablation::kWaveTrace) t_begin = t_last = wall_clock64();
     WorkItem it;
     while (pop_item(sw, d_next, lane, it)) {
-#ifdef RT_WAVE_TRACE
-        t_last = wall_clock64();
-        ++n_done;
-#endif
+        if constexpr (Ablation::kWaveTrace) {
+            t_last = wall_clock64();
+            ++n_done;
+        }
         const double tau = it.tau;
         Cfg cfg = cfg0;  // this atmosphere's table (wave-uniform)
         cfg.table_base = (int32_t)(it.table * (uint32_t)cfg0.n_wl);
@@ -412,15 +412,15 @@ __global__ __launch_bounds__(kWalkBlock) void walk_kernel(const Cfg cfg0, const 
             store_chunk(acc, it, hist, lane, nmu, nd, sw.n_atm, d_chunk_sums, d_counts, d_mu_hist, d_depth);
         }
     }
-#ifdef RT_WAVE_TRACE
-    if (lane == 0) {
-        unsigned long long* t = g_wave_trace + 4 * (size_t)(blockIdx.x * kWavesPerBlock + wave);
-        t[0] = t_begin;
-        t[1] = t_last;  // start of this wave's last chunk
-        t[2] = wall_clock64();
-        t[3] = n_done;
+    if constexpr (Ablation::kWaveTrace) {
+        if (lane == 0) {
+            unsigned long long* t = g_wave_trace + 4 * (size_t)(blockIdx.x * kWavesPerBlock + wave);
+            t[0] = t_begin;
+            t[1] = t_last;  // start of this wave's last chunk
+            t[2] = wall_clock64();
+            t[3] = n_done;
+        }
     }
-#endif
 }
 
 // Zeroes what a sweep accumulates into with atomics: the queue counter, the tally copies and the depth arrays.

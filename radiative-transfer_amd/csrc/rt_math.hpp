@@ -11,6 +11,19 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#ifdef RT_ABLATION
+#include "../../tools/ablation/ablation.hpp"  // timing experiments; such a build reports another ABI version
+#else
+namespace rt {
+struct Ablation {  // the product's values of the switches the timing experiments vary
+    static constexpr int kPhiloxRounds = 10;
+    static constexpr bool kUniform53 = false, kPlainFma = false, kSqrtGeneral = false, kDivGeneral = false, kWaveTrace = false;
+    static constexpr int kAbiTag = 0;
+    static bool chunk_rule(unsigned&, unsigned&) { return false; }
+};
+}  // namespace rt
+#endif
+
 namespace rt {
 
 // ---------------------------------------------------------------------------
@@ -23,13 +36,10 @@ namespace rt {
 // step is the two-address v_fmac_f64, which first copies the coefficient into the destination: one extra
 // 4-cycle v_mov_b64 per step.
 __device__ __forceinline__ double fma_step(double a, double b, double c) {
-#ifdef RT_PLAIN_FMA
-    return fma(a, b, c);
-#else
+    if constexpr (Ablation::kPlainFma) return fma(a, b, c);
     double d;
     asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
     return d;
-#endif
 }
 
 constexpr int kLogTableEntries = 128;
@@ -163,9 +173,7 @@ __device__ __forceinline__ double cos_2pi(double u) {
 // sequence of the general fp64 square root without its range scaling.  NaN for x < 0.
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ double sqrt_unit(double x) {
-#ifdef RT_SQRT_GENERAL
-    return sqrt(x);
-#else
+    if constexpr (Ablation::kSqrtGeneral) return sqrt(x);
     const double r = __builtin_amdgcn_rsq(x);
     double y = x * r;
     double h = r * 0.5;
@@ -177,7 +185,6 @@ __device__ __forceinline__ double sqrt_unit(double x) {
     d = fma(-y, y, x);
     y = fma(d, h, y);
     return x == 0.0 ? 0.0 : y;
-#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -187,9 +194,7 @@ __device__ __forceinline__ double sqrt_unit(double x) {
 // d = 0 gives NaN (the general division gives inf or NaN there).
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ double div_unit(double n, double d) {
-#ifdef RT_DIV_GENERAL
-    return n / d;
-#else
+    if constexpr (Ablation::kDivGeneral) return n / d;
     double r = __builtin_amdgcn_rcp(d);
     double e = fma(-d, r, 1.0);
     r = fma(r, e, r);
@@ -198,7 +203,6 @@ __device__ __forceinline__ double div_unit(double n, double d) {
     const double q = n * r;
     const double res = fma(-d, q, n);
     return fma(res, r, q);
-#endif
 }
 
 }  // namespace rt

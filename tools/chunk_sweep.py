@@ -1,4 +1,5 @@
-"""Chunk-length experiment (RT_AMD_CHUNK=thin,thick is read by the library at load, so one subprocess per rule):
+"""Chunk-length experiment with an experiment build of the library (-DRT_ABLATION; RT_AMD_LIB names it,
+RT_AMD_ALLOW_ABLATION=1): RT_AMD_CHUNK=thin,thick is read at load, so one subprocess per rule:
 walk-kernel time of the headline sweep on one rank and of two of the eight shares of an 8-rank job."""
 import importlib
 import os

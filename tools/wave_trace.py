@@ -1,6 +1,6 @@
 """When do the waves of the persistent walk kernel finish?  Needs the tracing build of the library:
-    hipcc ... -DRT_WAVE_TRACE -o radiative-transfer_amd/csrc/variants/trace.so
-    RT_AMD_LIB=.../trace.so python tools/wave_trace.py [world] [photons]
+    hipcc ... -DRT_ABLATION -DRT_ABL_WAVE_TRACE -o radiative-transfer_amd/csrc/variants/trace.so
+    RT_AMD_ALLOW_ABLATION=1 RT_AMD_LIB=.../trace.so python tools/wave_trace.py [world] [photons]
 Prints, for one rank's share of the headline sweep, the distribution of the waves' end times and of the length of
 their last chunk, relative to the launch's span (100 MHz clock)."""
 import ctypes as C
