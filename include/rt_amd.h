@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 4
+#define RT_ABI_VERSION 5
 
 typedef enum rt_status {
     RT_OK = 0,
@@ -157,6 +157,15 @@ typedef struct rt_params {
     int32_t geometry;              /* RT_GEOM_* */
     const int32_t* table_of_atm;   /* [n_atm] which table of rt_set_tables_multi an atmosphere uses; NULL = table 0 */
     double shell_inner;            /* RT_GEOM_SHELL: inner radius in units of the shell's thickness (> 0) */
+    double* escaped_mu;            /* opt-in, NULL = off: one double per photon, atmosphere after atmosphere in the
+                                      caller's order (atmosphere a starts at sum of n_photons[0..a-1]); photon i of an
+                                      atmosphere gets the cosine it left with if the reference would have put it into
+                                      RunPhotons' escaped_mu list (MC code.py:690-693, :779: the second escape test;
+                                      Numpy_random_walk.py:336-343: every escape), NaN otherwise.  A HOST array for
+                                      rt_run, a DEVICE array for rt_run_device / rt_run_device_static; only the
+                                      entries of this rank's slabs are written.  The sweep then runs the kernel that
+                                      reads its flags at run time.  Walk only, not rt_replay (whose per-photon trace
+                                      has the same information). */
 } rt_params;
 
 /* Host-side result arrays of one sweep; any pointer may be NULL to skip it. */
@@ -232,7 +241,7 @@ int rt_run_device(rt_ctx* ctx, const rt_params* p, void* d_slab_sums, void* d_co
  * library holds on every GPU it runs on from load to process exit, and the call itself allocates nothing on the
  * device or the host and frees nothing; its kernel is not timed (rt_kernel_time does not see it).
  * Limits (RT_ERR_LIMIT beyond them, before anything is enqueued): n_atm <= 4096, and the work memory within the
- * array: 52 * n_atm bytes of plan, up to 8 MiB of tally copies (8 * n_atm * (RT_NCNT + n_mu_bins + 1) bytes each, as
+ * array: 60 * n_atm bytes of plan, up to 8 MiB of tally copies (8 * n_atm * (RT_NCNT + n_mu_bins + 1) bytes each, as
  * many as fit, at most 64) and 80 bytes per chunk of this rank's slabs (a chunk is 8192 photon ids for slabs of at
  * least 250 000 ids, shorter below) <= 33554432 bytes in all -- the headline sweep (100 atmospheres x 2e7 photons on
  * one GPU: 244 800 chunks) needs 21 MB of it.  rt_set_tables must have been called before (that call allocates).  All contexts of one GPU share the array: two static sweeps in flight on one GPU at the same time,

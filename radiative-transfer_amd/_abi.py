@@ -11,7 +11,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "csrc", "librt_amd.so")
 
-RT_ABI_VERSION = 4
+RT_ABI_VERSION = 5
 
 BOUNDARY = {"reflect": 0, "absorb": 1, "reemit": 2}
 SCATTER = {"hg": 0, "iso": 1, "draine": 2, "draine_exact": 3}
@@ -41,7 +41,7 @@ class RtParams(C.Structure):
         ("monochromatic_wl", C.c_double), ("alpha", C.c_double), ("h", C.c_double),
         ("tau_atm", c_double_p), ("n_photons", c_u64_p),
         ("rng_mode", C.c_int32), ("geometry", C.c_int32), ("table_of_atm", C.POINTER(C.c_int32)),
-        ("shell_inner", C.c_double),
+        ("shell_inner", C.c_double), ("escaped_mu", c_double_p),
     ]
 
 

@@ -86,6 +86,8 @@ struct rt_ctx {
     DevBuf<unsigned char> d_work;  // plan + item prefix + queue counter + chunk partial sums (see WorkLayout)
     unsigned char* static_scratch = nullptr;  // this device's copy of the static work array (rt_run_device_static)
     std::vector<int> order;
+    std::vector<unsigned long long> mu_base;
+    DevBuf<double> d_escaped_mu;  // rt_run's device copy of rt_params.escaped_mu
     // pinned staging for the plan upload: the copy is asynchronous, `staged` says when the host side may be reused
     void* h_stage = nullptr;
     size_t h_stage_bytes = 0;
@@ -166,6 +168,7 @@ rt::Cfg make_cfg(const rt_ctx* ctx, const rt_params* p) {
     c.n_wl = ctx->n_wl;
     c.mono_index = -1;
     c.log_table = ctx->d_log_table.p;
+    c.escaped_mu = p->escaped_mu;  // a device address here (rt_run substitutes its own buffer for the caller's host array)
     return c;
 }
 
@@ -217,7 +220,7 @@ void drain_events(rt_ctx* ctx) {
 // is one, else the kernel that reads every flag at run time.
 rt::WalkVariant pick_variant(const rt_params* p, const rt::Cfg& cfg) {
     const bool packed = p->rng_mode == RT_RNG_PHILOX32X4;
-    const bool slab = p->geometry == RT_GEOM_SLAB && !p->abs_only;
+    const bool slab = p->geometry == RT_GEOM_SLAB && !p->abs_only && !p->escaped_mu;
     const bool mc = p->loop_order == RT_ORDER_MC, reflect = p->boundary == RT_BOUNDARY_REFLECT, hg = p->scatter == RT_SCATTER_HG;
     const bool depth = p->n_depth_bins > 0;
     if (slab && mc && reflect && hg && !depth) {
@@ -307,7 +310,10 @@ int enqueue_sweep(rt_ctx* ctx, const rt_params* p, void* d_slab_sums, void* d_co
     // ---- plan: heaviest atmospheres first, chunked per slab ----
     const size_t na = (size_t)p->n_atm;
     const uint32_t owned = (uint32_t)(n_slabs / world);
-    if (ctx->order.size() < na) ctx->order.resize(na);  // (the static path never gets here: n_atm <= kStaticMaxAtm)
+    if (ctx->order.size() < na) {  // (never in the static path: n_atm <= kStaticMaxAtm)
+        ctx->order.resize(na);
+        ctx->mu_base.resize(na);
+    }
     int* order = ctx->order.data();
     std::iota(order, order + na, 0);
     std::sort(order, order + na, [&](int a, int b) {  // ties keep the caller's order (no scratch memory needed)
@@ -330,9 +336,17 @@ int enqueue_sweep(rt_ctx* ctx, const rt_params* p, void* d_slab_sums, void* d_co
     rt::PlanEntry* plan = static_cast<rt::PlanEntry*>(ctx->h_stage);
     uint32_t* prefix = reinterpret_cast<uint32_t*>(static_cast<char*>(ctx->h_stage) + up.prefix_off);
     unsigned long long items = 0;
+    if (p->escaped_mu) {  // atmosphere a's photons start at the sum of the photon counts before it, in the caller's order
+        unsigned long long at = 0;
+        for (int a = 0; a < p->n_atm; ++a) {
+            ctx->mu_base[(size_t)a] = at;
+            at += p->n_photons[a];
+        }
+    }
     for (int k = 0; k < p->n_atm; ++k) {
         const int a = order[k];
         rt::PlanEntry& pl = plan[k];
+        pl.mu_base = p->escaped_mu ? ctx->mu_base[(size_t)a] : 0ull;
         pl.tau = p->tau_atm[a];
         pl.n_photons = p->n_photons[a];
         pl.slab_len = (pl.n_photons + (unsigned long long)n_slabs - 1) / (unsigned long long)n_slabs;
@@ -479,6 +493,7 @@ int rt_create(rt_ctx** out, int device_id) {
             return fail(RT_ERR_DEVICE, "static work array / staging buffer: %s", hipGetErrorString(e));
         }
         ctx->order.resize(kStaticMaxAtm);
+        ctx->mu_base.resize(kStaticMaxAtm);
     }
     // logarithm table for the kernels' ln(): c_j = 1 + (j + 1/2)/128, inv_c = fl(1/c_j), l = -ln(inv_c)
     std::vector<rt::LogTableEntry> tab(rt::kLogTableEntries);
@@ -511,6 +526,7 @@ int rt_destroy(rt_ctx* ctx) {
     ctx->d_lam.release();
     ctx->d_log_table.release();
     ctx->d_work.release();
+    ctx->d_escaped_mu.release();
     if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
     if (ctx->staged) (void)hipEventDestroy(ctx->staged);
     ctx->d_slab_sums.release();
@@ -622,9 +638,22 @@ int rt_run(rt_ctx* ctx, const rt_params* p, rt_tallies* out) {
     RT_HIP(ctx->d_counts.reserve(na * RT_NCNT));
     RT_HIP(ctx->d_mu_hist.reserve(na * nmu));
     if (nd) RT_HIP(ctx->d_depth.reserve(2 * na * nd));
-    rc = rt_run_device(ctx, p, ctx->d_slab_sums.p, ctx->d_counts.p, ctx->d_mu_hist.p, nd ? ctx->d_depth.p : nullptr,
+    rt_params run = *p;
+    size_t n_mu = 0;
+    if (p->escaped_mu) {  // the kernel writes a device array; the caller's host array is filled from it below
+        for (size_t a = 0; a < na; ++a) n_mu += (size_t)p->n_photons[a];
+        const hipError_t e = ctx->d_escaped_mu.reserve(n_mu ? n_mu : 1);
+        if (e != hipSuccess)
+            return fail(RT_ERR_DEVICE, "escaped_mu: %zu bytes of device memory for %zu photons: %s", 8 * n_mu, n_mu, hipGetErrorString(e));
+        // entries of slabs this rank does not walk are reported as NaN ("did not leave through the logged test here")
+        RT_HIP(hipMemsetAsync(ctx->d_escaped_mu.p, 0xff, sizeof(double) * n_mu, ctx->stream));
+        run.escaped_mu = ctx->d_escaped_mu.p;
+    }
+    rc = rt_run_device(ctx, &run, ctx->d_slab_sums.p, ctx->d_counts.p, ctx->d_mu_hist.p, nd ? ctx->d_depth.p : nullptr,
                        ctx->stream);
     if (rc) return rc;
+    if (p->escaped_mu && n_mu)
+        RT_HIP(hipMemcpyAsync(p->escaped_mu, ctx->d_escaped_mu.p, sizeof(double) * n_mu, hipMemcpyDeviceToHost, ctx->stream));
     std::vector<double> slab(na * n_slabs * RT_NSUM);
     RT_HIP(hipMemcpyAsync(slab.data(), ctx->d_slab_sums.p, sizeof(double) * slab.size(), hipMemcpyDeviceToHost,
                           ctx->stream));

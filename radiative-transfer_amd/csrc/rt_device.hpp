@@ -115,6 +115,7 @@ struct Cfg {
     int32_t n_wl, mono_index;
     int32_t table_base;  // first entry of the current atmosphere's table in rec / alias (several tables back to back)
     const LogTableEntry* log_table;  // kLogTableEntries entries in global memory (copied to LDS per workgroup)
+    double* escaped_mu;              // per-photon escape cosines (rt_params.escaped_mu), or null
 };
 
 // Which run flags a kernel has fixed at compile time.  Fixed<...>: loop order, lower boundary, scattering law and the

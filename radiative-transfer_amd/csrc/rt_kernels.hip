@@ -117,6 +117,7 @@ struct WorkItem {
     uint32_t atm;
     uint32_t table;
     size_t slot;  // where this chunk's partial sums go
+    unsigned long long mu_base;  // first entry of the atmosphere in Cfg::escaped_mu
 };
 
 // Pops the next item of the global queue (wave-uniform).  Returns false when the queue is empty.
@@ -156,6 +157,7 @@ __device__ __forceinline__ bool pop_item(const Sweep& sw, unsigned int* d_next, 
     it.atm = __builtin_amdgcn_readfirstlane(plan.atm);
     it.table = __builtin_amdgcn_readfirstlane(plan.table);
     it.slot = (size_t)uniform64((unsigned long long)plan.slot_base + (unsigned long long)j * plan.chunks + c);
+    it.mu_base = uniform64(plan.mu_base);
     return true;
 }
 
@@ -379,6 +381,12 @@ __global__ __launch_bounds__(kWalkBlock) void walk_kernel(const Cfg cfg0, const 
                     fate = fly_path<V>(cfg, ph, path, u_abs, 2, false, acc, hist, reemit, n_used);
                 }
                 if (fate != 0) {
+                    if (!FAST && cfg.escaped_mu) {  // the reference's escaped_mu list, photon by photon
+                        const unsigned long long gid = ((unsigned long long)src.id_hi << 32) | src.id_lo;
+                        const bool logged = fate == RT_FATE_ESCAPED_UNCOUNTED ||
+                                            (fate == RT_FATE_ESCAPED && (V::gray(cfg) || V::shell(cfg)));
+                        cfg.escaped_mu[it.mu_base + (gid - cfg.id_base)] = logged ? ph.mu : __builtin_nan("");
+                    }
                     retire<PLAIN, V>(cfg, ph, fate, acc, hist);
                     alive = false;
                 }

@@ -21,8 +21,9 @@ struct PlanEntry {
     uint32_t slot_base;  // first chunk-partial slot of this atmosphere
     uint32_t table;      // which of the context's tables this atmosphere uses
     uint32_t pad_;
+    unsigned long long mu_base;  // where this atmosphere's photons start in Cfg::escaped_mu
 };
-static_assert(sizeof(PlanEntry) == 48, "plan entries are uploaded as raw bytes");
+static_assert(sizeof(PlanEntry) == 56, "plan entries are uploaded as raw bytes");
 
 struct Sweep {
     const PlanEntry* plan;        // device, n_atm entries, heaviest atmospheres first

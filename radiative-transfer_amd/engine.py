@@ -91,11 +91,13 @@ class SweepResult:
 def make_params(tau, n_photons, *, boundary="reflect", scatter="hg", order="mc", rand_mu=0, abs_only=0,
                 n_mu_bins=10, n_depth_bins=0, max_events=0, n_slabs=8, rank=0, world=1, seed=DEFAULT_SEED,
                 photon_id_base=0, monochromatic=0.0, alpha=0.3, h=H_PLANCK, rng="philox52", table_of_atm=None,
-                geometry="slab", shell_inner=0.0):
+                geometry="slab", shell_inner=0.0, escaped_mu=False):
     """rng: "philox52" (default; 52-bit uniforms, two Philox blocks per loop iteration) or "philox32x4" (one
     block per iteration, 32-bit uniforms; faster, see rt_rng_mode in include/rt_amd.h).
     geometry: "slab" (the reference's) or "shell", a uniform spherical shell whose inner radius is `shell_inner`
-    thicknesses (see RT_GEOM_SHELL in include/rt_amd.h; use SweepResult.deposited_fraction() for its result)."""
+    thicknesses (see RT_GEOM_SHELL in include/rt_amd.h; use SweepResult.deposited_fraction() for its result).
+    escaped_mu: True asks Engine.run for the escape cosine of every photon (SweepResult.escaped_mu); an integer is taken
+    as the address of a caller-owned DEVICE array for Engine.run_device (rt_params.escaped_mu)."""
     if geometry not in abi.GEOMETRY:
         raise ValueError(f"geometry must be one of {sorted(abi.GEOMETRY)}")
     if rng not in abi.RNG:
@@ -112,6 +114,9 @@ def make_params(tau, n_photons, *, boundary="reflect", scatter="hg", order="mc",
                      int(world), int(seed), int(photon_id_base), float(monochromatic), float(alpha), float(h),
                      _dp(tau), _u64p(npn), abi.RNG[rng], abi.GEOMETRY[geometry], None, float(shell_inner))
     p._keep = (tau, npn)
+    p._want_escaped_mu = escaped_mu is True
+    if escaped_mu is not True and escaped_mu:
+        p.escaped_mu = C.cast(C.c_void_p(int(escaped_mu)), abi.c_double_p)
     if table_of_atm is not None:  # which of the tables given to Engine.set_tables (2-D columns) each atmosphere uses
         tab = np.ascontiguousarray(np.broadcast_to(np.atleast_1d(table_of_atm), tau.shape), dtype=np.int32)
         p.table_of_atm = tab.ctypes.data_as(C.POINTER(C.c_int32))
@@ -169,6 +174,17 @@ class Engine:
     def run(self, params):
         n_slabs = params.n_slabs if params.n_slabs > 0 else 8
         res = SweepResult(params.n_atm, params.n_mu_bins, params.n_depth_bins, n_slabs)
+        if getattr(params, "_want_escaped_mu", False):
+            counts = np.ctypeslib.as_array(params.n_photons, shape=(params.n_atm,)).astype(np.int64)
+            flat = np.full(int(counts.sum()), np.nan)
+            params.escaped_mu = _dp(flat)
+            self._check(self._lib.rt_run(self._ctx, C.byref(params), C.byref(res._c)))
+            params.escaped_mu = None
+            # per atmosphere: the cosines of the photons that left through the logged escape test, in photon order
+            # (RunPhotons' escaped_mu, MC code.py:693,779)
+            parts = np.split(flat, np.cumsum(counts)[:-1])
+            res.escaped_mu = [q[~np.isnan(q)] for q in parts]
+            return res
         self._check(self._lib.rt_run(self._ctx, C.byref(params), C.byref(res._c)))
         return res
 

@@ -8,9 +8,9 @@ and defaults.  Differences a caller can see:
 
 * random numbers come from Philox4x32-10 keyed by ``seed`` and the photon index, not from NumPy's
   global Mersenne Twister, so runs are reproducible and independent of the number of GPUs;
-* ``escaped_mu`` is returned as a histogram (``MuHistogram``) instead of one float per escaped
-  photon -- the reference's only use of the list is to histogram it
-  (Numpy_random_walk.py:436);
+* ``escaped_mu`` is returned as a histogram (``MuHistogram``) by default -- the reference's only
+  use of the list is to histogram it (Numpy_random_walk.py:436); ``return_escaped_mu=True`` returns
+  the reference's float array, one cosine per escaped photon (in photon order, not escape order);
 * a wavelength without a table entry, an unknown ``boundary`` and similar input errors raise
   instead of printing a message or looping forever (MC code.py:571, :403-408).
 """
@@ -87,7 +87,7 @@ def _tables_for(PDF, Range, Grain_data, monochromatic):
 
 def run_sweep(tau_list, num_photons, boundary, scatter, PDF, Range, Grain_data, *, rand_mu=False, abs_only=False,
               monochromatic=0, h=H_PLANCK, order="mc", seed=DEFAULT_SEED, photon_id_base=0, n_mu_bins=10,
-              n_depth_bins=0, max_events=0, alpha=0.3, geometry="slab", shell_inner=0.0, engine=None):
+              n_depth_bins=0, max_events=0, alpha=0.3, geometry="slab", shell_inner=0.0, engine=None, escaped_mu=False):
     """All atmospheres of tau_list in one kernel launch; returns the engine's SweepResult.
     scatter may also be 'draine_exact' and geometry 'shell' (extensions, see include/rt_amd.h)."""
     eng = engine or default_engine()
@@ -97,29 +97,34 @@ def run_sweep(tau_list, num_photons, boundary, scatter, PDF, Range, Grain_data, 
                       abs_only=int(bool(abs_only)), n_mu_bins=n_mu_bins, n_depth_bins=n_depth_bins,
                       max_events=max_events, seed=seed, photon_id_base=photon_id_base,
                       monochromatic=float(monochromatic) if monochromatic else 0.0, alpha=alpha, h=h,
-                      geometry=geometry, shell_inner=shell_inner)
+                      geometry=geometry, shell_inner=shell_inner, escaped_mu=bool(escaped_mu))
     return eng.run(prm)
 
 
 def RunPhotons(tau_atm, num_photons, boundary, scatter, PDF, Range, Grain_data, *, rand_mu=False, abs_only=False,
-               monochromatic=0, h=H_PLANCK, seed=DEFAULT_SEED, n_mu_bins=10, engine=None):
-    """MC code.py:620.  Returns (escaped_mu, boundary_momentum, escaped_momentum, initial_momentum, scatter_count)."""
+               monochromatic=0, h=H_PLANCK, seed=DEFAULT_SEED, n_mu_bins=10, engine=None, return_escaped_mu=False):
+    """MC code.py:620.  Returns (escaped_mu, boundary_momentum, escaped_momentum, initial_momentum, scatter_count).
+    escaped_mu is a MuHistogram, or with return_escaped_mu=True the reference's own form: a float array with the
+    cosine of every photon that left through the logged escape test (MC code.py:690-693)."""
     res = run_sweep([tau_atm], num_photons, boundary, scatter, PDF, Range, Grain_data, rand_mu=rand_mu,
-                    abs_only=abs_only, monochromatic=monochromatic, h=h, seed=seed, n_mu_bins=n_mu_bins, engine=engine)
-    return (MuHistogram(res.mu_hist[0]), float(res.boundary_momentum[0]), float(res.escaped_momentum[0]),
+                    abs_only=abs_only, monochromatic=monochromatic, h=h, seed=seed, n_mu_bins=n_mu_bins, engine=engine,
+                    escaped_mu=return_escaped_mu)
+    emu = res.escaped_mu[0] if return_escaped_mu else MuHistogram(res.mu_hist[0])
+    return (emu, float(res.boundary_momentum[0]), float(res.escaped_momentum[0]),
             float(res.initial_momentum[0]), int(res.scatter_count[0]))
 
 
 def RunPhotonsGray(tau_atm, num_photons, boundary, albedo, scatter, g, *, rand_mu=0, alpha=0.3, seed=DEFAULT_SEED,
-                   n_mu_bins=10, engine=None):
+                   n_mu_bins=10, engine=None, return_escaped_mu=False):
     """Numpy_random_walk.py:280 (scalar albedo and g, lambda = 1, h = 1, boundary tested before escape).
     Returns (escaped_mu, boundary_momentum, escaped_momentum, initial_momentum)."""
     grain = {"WL": np.array([1.0]), "g": np.array([float(g)]), "Albedo": np.array([float(albedo)]),
              "Scale": np.array([1.0])}
     res = run_sweep([tau_atm], num_photons, boundary, scatter, None, None, grain, rand_mu=rand_mu, monochromatic=1.0,
-                    h=1.0, order="gray", seed=seed, n_mu_bins=n_mu_bins, alpha=alpha, engine=engine)
-    return (MuHistogram(res.mu_hist[0]), float(res.boundary_momentum[0]), float(res.escaped_momentum[0]),
-            float(res.initial_momentum[0]))
+                    h=1.0, order="gray", seed=seed, n_mu_bins=n_mu_bins, alpha=alpha, engine=engine,
+                    escaped_mu=return_escaped_mu)
+    emu = res.escaped_mu[0] if return_escaped_mu else MuHistogram(res.mu_hist[0])
+    return (emu, float(res.boundary_momentum[0]), float(res.escaped_momentum[0]), float(res.initial_momentum[0]))
 
 
 # ----------------------------------------------------------------------------------------------

@@ -1,0 +1,79 @@
+"""Opt-in per-photon escape cosines (rt_params.escaped_mu): the reference's RunPhotons returns one float per photon
+that left through its logged escape test (MC code.py:690-693, :779; Numpy_random_walk.py:336-343, :408).  Checked
+against the reference's own list on the replay goldens (as a multiset: the reference appends in escape order, the
+device reports in photon order), and photon by photon against the C oracle on production Philox streams."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+def small_table(n=64):
+    wl = np.round(np.linspace(0.1, 1.0, n), 4)
+    return wl, np.linspace(0.3, 0.8, n), np.linspace(0.4, 0.95, n), np.linspace(2.0, 0.5, n), np.linspace(1.0, 0.1, n) / n
+
+
+def test_replay_goldens_give_the_reference_list(rt, engine):
+    """The reference's escaped_mu of every replay case = the final cosines of the photons whose fate is the logged
+    escape, as a multiset (same uniforms, same photons: the values agree to the replay tolerance)."""
+    from oracle import philox
+    A = rt._abi
+    G = np.load(os.path.join(GOLDEN, "walk_replay.npz"))
+    checked = 0
+    for name in [str(n) for n in G["names"]]:
+        c = {k.split("/", 1)[1]: G[k] for k in G.files if k.startswith(name + "/")}
+        n, order = int(c["n"]), str(c["order"])
+        xi = philox.walk_matrix(n, int(c["ref_draws"].max()), 0, int(c["seed"]))
+        prm = rt.make_params(float(c["tau"]), n, boundary=str(c["boundary"]), scatter=str(c["scatter"]), order=order,
+                             abs_only=int(c["abs_only"]), h=(1.0 if order == "gray" else rt.H_PLANCK), n_mu_bins=10)
+        res, trace = engine.replay(prm, xi, c["lam"], c["g"], c["albedo"], c["scale"], c["mu0"])
+        logged = trace["fate"] == (A.FATE_ESCAPED if order == "gray" else A.FATE_ESCAPED_UNCOUNTED)
+        got, want = np.sort(trace["final_mu"][logged]), np.sort(c["ref_escaped_mu"])
+        assert len(got) == len(want), name
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-12, err_msg=name)
+        checked += len(want)
+    assert checked > 1000
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(order="gray", h=1.0), dict(boundary="absorb"), dict(rank=1, world=2)])
+def test_walk_reports_every_photon(rt, engine, c_oracle, kw):
+    A = rt._abi
+    engine.set_tables(*small_table())
+    tau, n = np.array([0.3, 2.0, 8.0]), np.array([5000, 3001, 4000], dtype=np.uint64)
+    res = engine.run(rt.make_params(tau, n, n_mu_bins=10, escaped_mu=True, **kw))
+    assert "Runtime" in engine.last_kernel()
+    plain = engine.run(rt.make_params(tau, n, n_mu_bins=10, **kw))
+    assert np.array_equal(res.counts, plain.counts) and np.array_equal(res.mu_hist, plain.mu_hist)
+    np.testing.assert_allclose(res.sums, plain.sums, rtol=1e-12)
+    for a in range(3):
+        emu = res.escaped_mu[a]
+        assert len(emu) == int(res.mu_hist[a].sum())            # the histogram is of exactly these values
+        bins = np.minimum(np.floor(10 * emu).astype(int), 10)
+        assert np.array_equal(np.bincount(bins, minlength=11), res.mu_hist[a].astype(np.int64))
+    # photon by photon against the oracle's trace of atmosphere 0 (same Philox streams)
+    okw = {k: v for k, v in kw.items()}
+    ref, tr = c_oracle.run(c_oracle.make_params(tau, n, n_mu_bins=10, **okw), *small_table(), trace=True)
+    gray = kw.get("order") == "gray"
+    logged = tr["fate"] == (A.FATE_ESCAPED if gray else A.FATE_ESCAPED_UNCOUNTED)
+    if kw.get("world", 1) > 1:   # the oracle's trace covers this rank's photons only: compare where it walked
+        walked = tr["fate"] != 0
+        logged &= walked
+    np.testing.assert_allclose(res.escaped_mu[0], tr["final_mu"][logged], rtol=0, atol=1e-12)
+    assert len(res.escaped_mu[0]) >= (0 if kw.get("boundary") == "absorb" else 20)  # no reflection, no second escape
+
+
+def test_reference_shaped_wrapper_returns_the_float_array(rt, engine):
+    import importlib
+    mc = importlib.import_module("radiative-transfer_amd.mc")
+    wl, g, alb, sc, pdf = small_table()
+    grain = {"WL": wl, "g": g, "Albedo": alb, "Scale": sc}
+    emu, B, E, I, count = mc.RunPhotons(3.0, 20000, "reflect", "hg", pdf, wl, grain, engine=engine, return_escaped_mu=True)
+    hist, B2, E2, I2, count2 = mc.RunPhotons(3.0, 20000, "reflect", "hg", pdf, wl, grain, engine=engine)
+    assert isinstance(emu, np.ndarray) and emu.dtype == np.float64 and len(emu) == len(hist) and count == count2
+    assert np.all((emu > 0) & (emu <= 1)) and (B, E, I) == pytest.approx((B2, E2, I2), rel=1e-12)
+    emu_g, *_ = mc.RunPhotonsGray(2.0, 20000, "reflect", 0.9, "hg", 0.5, engine=engine, return_escaped_mu=True)
+    assert len(emu_g) > 10000     # in the gray script every escape is logged
