@@ -41,8 +41,12 @@ typedef enum rt_status {
 enum { RT_BOUNDARY_REFLECT = 0, RT_BOUNDARY_ABSORB = 1, RT_BOUNDARY_REEMIT = 2 };
 /* scattering law, MC code.py:732-760 and Numpy_random_walk.py:369-396 */
 enum { RT_SCATTER_HG = 0, RT_SCATTER_ISO = 1, RT_SCATTER_DRAINE = 2, RT_SCATTER_DRAINE_EXACT = 3 };
-/* RT_SCATTER_DRAINE restates the reference's rejection sampler (Numpy_random_walk.py:106-130) photon by photon,
- * including its defect: candidates are accepted where pdf(mu) > y with y uniform on [0,1), so the density is
+/* RT_SCATTER_DRAINE restates the reference's rejection sampler (Numpy_random_walk.py:106-130) photon by photon --
+ * a deliberate difference in pairing: the reference draws candidates for all scattering photons in batches and hands
+ * the accepted cosines to the photons in acceptance order (and may return more cosines than photons), here every
+ * photon runs the same accept / reject test on pairs (y, candidate) of its own stream until one is accepted.  Each
+ * accepted cosine is an independent draw from the same law either way; that law is pinned to the reference's own
+ * output (histograms of 1e6 cosines, tests/test_draine_reference_law.py).  It keeps the reference's defect: candidates are accepted where pdf(mu) > y with y uniform on [0,1), so the density is
  * clipped wherever pdf > 1 and the sampler is slow where pdf << 1.  Gray loop order only, as in the reference.
  * RT_SCATTER_DRAINE_EXACT (no counterpart in the reference, which marks its sampler "not currently functioning",
  * MC code.py:1006) draws from the same phase function
