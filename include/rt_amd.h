@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 5
+#define RT_ABI_VERSION 6
 
 typedef enum rt_status {
     RT_OK = 0,
@@ -253,6 +253,28 @@ int rt_run_device(rt_ctx* ctx, const rt_params* p, void* d_slab_sums, void* d_co
  * caller. */
 int rt_run_device_static(rt_ctx* ctx, const rt_params* p, void* d_slab_sums, void* d_counts, void* d_mu_hist,
                          void* d_depth, void* stream);
+
+/* ---- the collective, for callers without a Python runtime (one process per GPU) ----
+ * No counterpart in the reference (single process).  RCCL is opened at run time by these calls (librccl.so.1; a
+ * process that already has it loaded -- PyTorch ships one -- shares that copy) and is not a link dependency.
+ *   rt_comm_unique_id  on one process: fills id[RT_COMM_ID_BYTES] (an ncclUniqueId); the caller hands the bytes to
+ *                      the other processes by whatever it launches them with (file, environment, MPI, a socket);
+ *   rt_comm_init       on every process: joins the communicator as `rank` of `world` on the context's GPU
+ *                      (collective: returns when all ranks have called it);
+ *   rt_run_allreduce   rt_run_device for the slabs of this process's rank (rank / world of the communicator replace
+ *                      p->rank / p->world; n_slabs must be a multiple of world) followed by ONE all-reduce on the
+ *                      same stream, not synchronised.  d_tallies is one device buffer of 64-bit words,
+ *                          [n_atm][n_slabs][RT_NSUM] doubles | [n_atm][RT_NCNT] u64 | [n_atm][n_mu_bins + 1] u64,
+ *                      summed as 64-bit integers: every slab entry is non-zero on exactly one rank and zero bits on
+ *                      the others, so the doubles come back unchanged, and summing the slab axis in index order
+ *                      gives the same bits on any number of GPUs.  With n_depth_bins > 0, d_depth
+ *                      ([2][n_atm][n_depth_bins] doubles) gets a second, floating-point all-reduce.
+ *   rt_comm_destroy    leaves the communicator (rt_destroy does it too). */
+#define RT_COMM_ID_BYTES 128
+int rt_comm_unique_id(void* id);
+int rt_comm_init(rt_ctx* ctx, int rank, int world, const void* id);
+int rt_comm_destroy(rt_ctx* ctx);
+int rt_run_allreduce(rt_ctx* ctx, const rt_params* p, void* d_tallies, void* d_depth, void* stream);
 
 /* Replay: photon i consumes xi[i*max_draws + j], j = 0,1,... instead of Philox, with its constants
  * given directly (what CreatePhotons would have put in its row).  Used to compare trajectories with

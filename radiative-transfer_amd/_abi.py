@@ -11,7 +11,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "csrc", "librt_amd.so")
 
-RT_ABI_VERSION = 5
+RT_ABI_VERSION = 6
 
 BOUNDARY = {"reflect": 0, "absorb": 1, "reemit": 2}
 SCATTER = {"hg": 0, "iso": 1, "draine": 2, "draine_exact": 3}
@@ -97,7 +97,8 @@ class RtPhotonTrace(C.Structure):
 
 EXPORTS = ["rt_abi_version", "rt_last_error", "rt_create", "rt_destroy", "rt_device_info", "rt_set_tables",
            "rt_run", "rt_run_device", "rt_replay", "rt_kernel_time", "rt_selftest_math", "rt_build_grain_tables",
-           "rt_shell_velocity", "rt_shell_rhs", "rt_set_tables_multi", "rt_run_device_static", "rt_last_kernel"]
+           "rt_shell_velocity", "rt_shell_rhs", "rt_set_tables_multi", "rt_run_device_static", "rt_last_kernel",
+           "rt_comm_unique_id", "rt_comm_init", "rt_comm_destroy", "rt_run_allreduce"]
 
 _lib = None
 
@@ -125,6 +126,10 @@ def load_library(path=None):
     lib.rt_run.argtypes = [vp, C.POINTER(RtParams), C.POINTER(RtTallies)]
     lib.rt_run_device.argtypes = [vp, C.POINTER(RtParams), vp, vp, vp, vp, vp]
     lib.rt_run_device_static.argtypes = [vp, C.POINTER(RtParams), vp, vp, vp, vp, vp]
+    lib.rt_comm_unique_id.argtypes = [vp]
+    lib.rt_comm_init.argtypes = [vp, C.c_int, C.c_int, vp]
+    lib.rt_comm_destroy.argtypes = [vp]
+    lib.rt_run_allreduce.argtypes = [vp, C.POINTER(RtParams), vp, vp, vp]
     lib.rt_replay.argtypes = [vp, C.POINTER(RtParams), C.c_int64, C.c_int32, c_double_p, c_double_p, c_double_p,
                               c_double_p, c_double_p, c_double_p, C.POINTER(RtTallies), C.POINTER(RtPhotonTrace)]
     lib.rt_build_grain_tables.argtypes = [vp, C.POINTER(RtGrainSet), C.c_double, C.c_double, C.c_double, C.c_int32,

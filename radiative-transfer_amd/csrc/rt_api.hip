@@ -3,6 +3,8 @@
 // Host side only; the kernels are in rt_kernels.hip.  Everything here talks to one GPU through
 // the HIP runtime.  There is no CPU implementation of the walk in this library.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types and prototypes only: the library is opened at run time (rt_comm_init), not linked
 
 #include <algorithm>
 #include <cmath>
@@ -99,6 +101,9 @@ struct rt_ctx {
     int blocks_per_cu[rt::kWalkVariants] = {};  // occupancy of each walk-kernel variant for blocks_lds bytes of LDS
     size_t blocks_lds[rt::kWalkVariants] = {};
     int last_variant = -1;  // the variant the last sweep ran (rt_last_kernel)
+    // the collective (rt_comm_init): one RCCL communicator per context, rank and size as given there
+    ncclComm_t comm = nullptr;
+    int comm_rank = 0, comm_world = 1;
     // kernel timing
     std::vector<EventPair> events;
     size_t events_used = 0;
@@ -517,6 +522,7 @@ int rt_destroy(rt_ctx* ctx) {
     if (!ctx) return RT_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    (void)rt_comm_destroy(ctx);
     for (auto& e : ctx->events) {
         (void)hipEventDestroy(e.a);
         (void)hipEventDestroy(e.b);
@@ -1031,6 +1037,114 @@ int rt_selftest_math(rt_ctx* ctx, int64_t n, const double* u, double* out_log, d
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     d.release();
     if (e != hipSuccess) return fail(RT_ERR_DEVICE, "selftest failed: %s", hipGetErrorString(e));
+    return RT_OK;
+}
+
+// ---- the collective: RCCL, opened at run time ----
+namespace {
+
+struct Rccl {
+    void* handle = nullptr;
+    decltype(&ncclGetUniqueId) get_unique_id = nullptr;
+    decltype(&ncclCommInitRank) comm_init_rank = nullptr;
+    decltype(&ncclCommDestroy) comm_destroy = nullptr;
+    decltype(&ncclAllReduce) all_reduce = nullptr;
+    decltype(&ncclGetErrorString) error_string = nullptr;
+};
+
+// librccl.so.1 is opened on first use, so that a process that never uses the collective does not load RCCL, and a
+// process that already has an RCCL of that name loaded (PyTorch ships one) shares it instead of loading a second.
+const Rccl* rccl() {
+    static Rccl r;
+    static bool tried = false;
+    if (!tried) {
+        tried = true;
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            r.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (r.handle) break;
+        }
+        if (r.handle) {
+            r.get_unique_id = reinterpret_cast<decltype(r.get_unique_id)>(dlsym(r.handle, "ncclGetUniqueId"));
+            r.comm_init_rank = reinterpret_cast<decltype(r.comm_init_rank)>(dlsym(r.handle, "ncclCommInitRank"));
+            r.comm_destroy = reinterpret_cast<decltype(r.comm_destroy)>(dlsym(r.handle, "ncclCommDestroy"));
+            r.all_reduce = reinterpret_cast<decltype(r.all_reduce)>(dlsym(r.handle, "ncclAllReduce"));
+            r.error_string = reinterpret_cast<decltype(r.error_string)>(dlsym(r.handle, "ncclGetErrorString"));
+            if (!r.get_unique_id || !r.comm_init_rank || !r.comm_destroy || !r.all_reduce || !r.error_string) r.handle = nullptr;
+        }
+    }
+    return r.handle ? &r : nullptr;
+}
+
+#define RT_RCCL(lib, call)                                                                          \
+    do {                                                                                            \
+        ncclResult_t r_ = (call);                                                                   \
+        if (r_ != ncclSuccess) return fail(RT_ERR_DEVICE, "%s failed: %s", #call, (lib)->error_string(r_)); \
+    } while (0)
+
+}  // namespace
+
+static_assert(sizeof(ncclUniqueId) == RT_COMM_ID_BYTES, "rt_comm_unique_id hands out an ncclUniqueId");
+
+int rt_comm_unique_id(void* id) {
+    if (!id) return fail(RT_ERR_INVALID, "id is NULL");
+    const Rccl* lib = rccl();
+    if (!lib) return fail(RT_ERR_DEVICE, "librccl.so.1 could not be opened: %s", dlerror());
+    ncclUniqueId u;
+    RT_RCCL(lib, lib->get_unique_id(&u));
+    memcpy(id, &u, sizeof u);
+    return RT_OK;
+}
+
+int rt_comm_init(rt_ctx* ctx, int rank, int world, const void* id) {
+    if (!ctx || !id) return fail(RT_ERR_INVALID, "NULL argument");
+    if (world < 1 || rank < 0 || rank >= world) return fail(RT_ERR_INVALID, "rank %d not in [0,%d)", rank, world);
+    if (ctx->comm) return fail(RT_ERR_STATE, "the context already has a communicator");
+    const Rccl* lib = rccl();
+    if (!lib) return fail(RT_ERR_DEVICE, "librccl.so.1 could not be opened: %s", dlerror());
+    RT_HIP(hipSetDevice(ctx->device));
+    ncclUniqueId u;
+    memcpy(&u, id, sizeof u);
+    RT_RCCL(lib, lib->comm_init_rank(&ctx->comm, world, u, rank));
+    ctx->comm_rank = rank;
+    ctx->comm_world = world;
+    return RT_OK;
+}
+
+int rt_comm_destroy(rt_ctx* ctx) {
+    if (!ctx) return fail(RT_ERR_INVALID, "ctx is NULL");
+    if (!ctx->comm) return RT_OK;
+    const Rccl* lib = rccl();
+    (void)hipSetDevice(ctx->device);
+    const ncclResult_t r = lib ? lib->comm_destroy(ctx->comm) : ncclSuccess;
+    ctx->comm = nullptr;
+    ctx->comm_rank = 0;
+    ctx->comm_world = 1;
+    if (r != ncclSuccess) return fail(RT_ERR_DEVICE, "ncclCommDestroy failed: %s", lib->error_string(r));
+    return RT_OK;
+}
+
+int rt_run_allreduce(rt_ctx* ctx, const rt_params* p, void* d_tallies, void* d_depth, void* stream_v) {
+    if (!ctx) return fail(RT_ERR_INVALID, "ctx is NULL");
+    if (!p) return fail(RT_ERR_INVALID, "params is NULL");
+    if (!ctx->comm) return fail(RT_ERR_STATE, "rt_comm_init must be called before rt_run_allreduce");
+    if (!d_tallies) return fail(RT_ERR_INVALID, "d_tallies is NULL");
+    if (p->n_atm < 1) return fail(RT_ERR_INVALID, "n_atm must be >= 1 (got %d)", p->n_atm);
+    const int n_slabs = p->n_slabs > 0 ? p->n_slabs : 8;
+    const size_t na = (size_t)p->n_atm, nmu = (size_t)(p->n_mu_bins > 0 ? p->n_mu_bins : 0) + 1;
+    const size_t n_slab = na * n_slabs * RT_NSUM, n_cnt = na * RT_NCNT, n_hist = na * nmu;
+    unsigned long long* words = static_cast<unsigned long long*>(d_tallies);
+    rt_params run = *p;  // the communicator says which slabs this process walks
+    run.rank = ctx->comm_rank;
+    run.world = ctx->comm_world;
+    const int rc = enqueue_sweep(ctx, &run, words, words + n_slab, words + n_slab + n_cnt, d_depth, stream_v, false);
+    if (rc) return rc;
+    const Rccl* lib = rccl();
+    hipStream_t stream = (hipStream_t)stream_v;
+    // One collective: every slab-sum word is non-zero on exactly one rank and all-zero bits on the others, so the
+    // integer sum of the bit patterns returns that rank's double unchanged; counts and histogram add as integers.
+    RT_RCCL(lib, lib->all_reduce(words, words, n_slab + n_cnt + n_hist, ncclInt64, ncclSum, ctx->comm, stream));
+    if (p->n_depth_bins > 0)  // accumulated with floating-point atomics on every rank: a floating-point sum of its own
+        RT_RCCL(lib, lib->all_reduce(d_depth, d_depth, 2 * na * (size_t)p->n_depth_bins, ncclDouble, ncclSum, ctx->comm, stream));
     return RT_OK;
 }
 

@@ -197,6 +197,25 @@ class Engine:
                                             C.c_void_p(depth_ptr) if depth_ptr else None,
                                             C.c_void_p(stream) if stream else None))
 
+    # ---- the library's own collective (RCCL opened by the library; no torch.distributed involved) ----
+    def comm_unique_id(self):
+        """128 bytes identifying a new communicator; create on one process, hand to the others, give to comm_init."""
+        buf = C.create_string_buffer(128)
+        self._check(self._lib.rt_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, rank, world, unique_id):
+        self._check(self._lib.rt_comm_init(self._ctx, int(rank), int(world), C.c_char_p(bytes(unique_id))))
+
+    def comm_destroy(self):
+        self._check(self._lib.rt_comm_destroy(self._ctx))
+
+    def run_allreduce(self, params, tallies_ptr, depth_ptr=None, stream=None):
+        """Sweep of this rank's slabs + one all-reduce of the packed tally buffer (layout: distributed.TallyBuffer)."""
+        self._check(self._lib.rt_run_allreduce(self._ctx, C.byref(params), C.c_void_p(tallies_ptr),
+                                               C.c_void_p(depth_ptr) if depth_ptr else None,
+                                               C.c_void_p(stream) if stream else None))
+
     def replay(self, params, xi, lam, g, albedo, scale, mu0):
         xi = np.ascontiguousarray(xi, dtype=np.float64)
         n, max_draws = xi.shape

@@ -106,3 +106,75 @@ def test_bench_launches_its_own_ranks_and_is_strong_scaled():
     for k in ("photons_per_atmosphere_global", "photon_histories_per_step", "flights_per_step", "events_per_step"):
         assert one["config"][k] == two["config"][k]
     assert two["value"] > 0 and two["roofline"]["kernel_launches"] == 2
+
+
+# ---- the library's own collective (rt_comm_*, rt_run_allreduce): RCCL opened by the library, no torch.distributed ----
+COMM_WORKER = r"""
+import importlib, os, sys, time
+import numpy as np
+import torch
+sys.path.insert(0, sys.argv[1])
+rank, world, id_file, out = int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]
+rt = importlib.import_module("radiative-transfer_amd")
+D = importlib.import_module("radiative-transfer_amd.distributed")
+dev = rank % torch.cuda.device_count()
+torch.cuda.set_device(dev)
+eng = rt.Engine(dev)
+if rank == 0:
+    uid = eng.comm_unique_id()
+    with open(id_file + ".tmp", "wb") as fh:
+        fh.write(uid)
+    os.rename(id_file + ".tmp", id_file)
+else:
+    for _ in range(600):
+        if os.path.exists(id_file):
+            break
+        time.sleep(0.1)
+    uid = open(id_file, "rb").read()
+eng.comm_init(rank, world, uid)
+n = 64
+wl = np.round(np.linspace(0.1, 1.0, n), 4)
+eng.set_tables(wl, np.linspace(0.3, 0.8, n), np.linspace(0.4, 0.9, n), np.linspace(2.0, 0.5, n), np.linspace(1.0, 0.1, n) / n)
+tau = np.array([0.05, 0.7, 9.0])
+prm = rt.make_params(tau, 300007, n_mu_bins=10, n_depth_bins=4)     # rank / world come from the communicator
+buf = D.TallyBuffer(torch, len(tau), 8, 10, torch.device("cuda", dev))
+depth = torch.zeros(2 * len(tau) * 4, dtype=torch.float64, device=buf.words.device)
+eng.run_allreduce(prm, buf.words.data_ptr(), depth.data_ptr(), torch.cuda.current_stream().cuda_stream)
+torch.cuda.synchronize()
+res = buf.result(depth, 4)
+np.savez(out % rank, sums=res.sums, slab=res.slab_sums, counts=res.counts, hist=res.mu_hist, dm=res.depth_momentum)
+eng.comm_destroy()
+eng.close()
+"""
+
+
+def _run_comm_ranks(world, tmp_path):
+    script = tmp_path / "comm_worker.py"
+    script.write_text(COMM_WORKER)
+    out = str(tmp_path / "comm_rank%d.npz")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(r), str(world), str(tmp_path / "rccl_id"), out], env=env)
+             for r in range(world)]
+    codes = [p.wait(timeout=300) for p in procs]
+    assert codes == [0] * world
+    return [np.load(out % r) for r in range(world)]
+
+
+def test_library_collective_single_rank(rt, engine, tmp_path):
+    """rt_comm_unique_id / rt_comm_init / rt_run_allreduce with a communicator of one: the whole path a C caller
+    uses (RCCL opened by the library, packed buffer, all-reduce on the sweep's stream), equal to rt_run bit for bit."""
+    one = _single(rt, engine)
+    (r,) = _run_comm_ranks(1, tmp_path)
+    assert np.array_equal(r["slab"], one.slab_sums) and np.array_equal(r["sums"], one.sums)
+    assert np.array_equal(r["counts"], one.counts) and np.array_equal(r["hist"], one.mu_hist)
+    np.testing.assert_allclose(r["dm"], one.depth_momentum, rtol=1e-12)
+
+
+def test_library_collective_two_gpus(rt, engine, tmp_path):
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    one = _single(rt, engine)
+    for r in _run_comm_ranks(2, tmp_path):
+        assert np.array_equal(r["slab"], one.slab_sums) and np.array_equal(r["sums"], one.sums)
+        assert np.array_equal(r["counts"], one.counts) and np.array_equal(r["hist"], one.mu_hist)
