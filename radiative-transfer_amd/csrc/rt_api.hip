@@ -229,8 +229,9 @@ rt::WalkVariant pick_variant(const rt_params* p, const rt::Cfg& cfg) {
     const bool mc = p->loop_order == RT_ORDER_MC, reflect = p->boundary == RT_BOUNDARY_REFLECT, hg = p->scatter == RT_SCATTER_HG;
     const bool depth = p->n_depth_bins > 0;
     if (slab && mc && reflect && hg && !depth) {
-        if (packed) return rt::kWalkBasePacked;
-        return (!p->rand_mu && cfg.mono_index < 0) ? rt::kWalkPlain : rt::kWalkBase;  // the reference's defaults throughout
+        const bool plain = !p->rand_mu && cfg.mono_index < 0;  // the reference's defaults throughout
+        if (packed) return plain ? rt::kWalkPlainPacked : rt::kWalkBasePacked;
+        return plain ? rt::kWalkPlain : rt::kWalkBase;
     }
     if (slab && !packed) {
         if (mc && reflect && hg && depth) return rt::kWalkDepth;

@@ -679,6 +679,7 @@ static WalkKernel walk_kernel_of(WalkVariant v) {
         case kWalkPlain: return walk_kernel<FixedBase, false, true>;
         case kWalkBase: return walk_kernel<FixedBase, false, false>;
         case kWalkBasePacked: return walk_kernel<FixedBase, true, false>;
+        case kWalkPlainPacked: return walk_kernel<FixedBase, true, true>;
         case kWalkDepth: return walk_kernel<FixedDepth, false, false>;
         case kWalkAbsorb: return walk_kernel<FixedAbsorb, false, false>;
         case kWalkReemit: return walk_kernel<FixedReemit, false, false>;
@@ -694,6 +695,7 @@ const char* walk_variant_name(WalkVariant v) {
         case kWalkPlain: return "walk_kernel<FixedBase, false, true>";
         case kWalkBase: return "walk_kernel<FixedBase, false, false>";
         case kWalkBasePacked: return "walk_kernel<FixedBase, true, false>";
+        case kWalkPlainPacked: return "walk_kernel<FixedBase, true, true>";
         case kWalkDepth: return "walk_kernel<FixedDepth, false, false>";
         case kWalkAbsorb: return "walk_kernel<FixedAbsorb, false, false>";
         case kWalkReemit: return "walk_kernel<FixedReemit, false, false>";

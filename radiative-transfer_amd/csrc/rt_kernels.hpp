@@ -57,6 +57,7 @@ enum WalkVariant {
     kWalkPlain,          // production: MC order, reflect, HG, no depth bins; rand_mu and monochromatic off as well
     kWalkBase,           // production flags; rand_mu / monochromatic read at run time
     kWalkBasePacked,     // production flags on the one-block random stream
+    kWalkPlainPacked,    // the same with rand_mu and monochromatic off at compile time
     kWalkDepth,          // production flags + depth-resolved deposition
     kWalkAbsorb,         // absorbing lower boundary
     kWalkReemit,         // re-emitting lower boundary

@@ -175,7 +175,8 @@ def test_which_kernel_serves_which_flags(rt, engine):
     engine.set_tables(*small_table())
     tau = np.array([0.5, 5.0])
     want = [(dict(), "FixedBase, false, true"), (dict(rand_mu=1), "FixedBase, false, false"),
-            (dict(rng="philox32x4"), "FixedBase, true, false"), (dict(n_depth_bins=8), "FixedDepth"),
+            (dict(rng="philox32x4"), "FixedBase, true, true"), (dict(rng="philox32x4", rand_mu=1), "FixedBase, true, false"),
+            (dict(n_depth_bins=8), "FixedDepth"),
             (dict(boundary="absorb"), "FixedAbsorb"), (dict(boundary="reemit"), "FixedReemit"),
             (dict(scatter="iso"), "FixedIso"), (dict(order="gray", h=1.0), "FixedGray"),
             (dict(abs_only=1), "Runtime, false"), (dict(boundary="absorb", n_depth_bins=8), "Runtime, false"),

@@ -17,8 +17,8 @@ def main(root, workload, photons):
                     tot[row["Counter_Name"]] = tot.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
     g = lambda k: tot.get(k, 0.0)
     out = {
-        "round": 1, "workload": workload, "photons_per_atmosphere": int(photons),
-        "source": "tools/pmc_traffic.sh (rocprofv3 --pmc, one pass per counter group, one walk_kernel<true, false, true> launch each)",
+        "workload": workload, "photons_per_atmosphere": int(photons),
+        "source": "tools/pmc_traffic.sh (rocprofv3 --pmc, one pass per counter group, one launch of the production walk kernel each)",
         "FETCH_SIZE_KB": g("FETCH_SIZE"), "WRITE_SIZE_KB": g("WRITE_SIZE"),
         "TCC_EA0_RDREQ": g("TCC_EA0_RDREQ_sum"), "TCC_EA0_RDREQ_32B": g("TCC_EA0_RDREQ_32B_sum"),
         "TCC_EA0_WRREQ": g("TCC_EA0_WRREQ_sum"), "TCC_EA0_WRREQ_64B": g("TCC_EA0_WRREQ_64B_sum"),
