@@ -148,6 +148,9 @@ int check_common(const rt_params* p) {
     return RT_OK;
 }
 
+// Scattering lanes of the lean kernels wait for this many of their kind (measured: tools/quorum_sweep.py).
+constexpr int kScatterQuorum = 8;
+
 rt::Cfg make_cfg(const rt_ctx* ctx, const rt_params* p) {
     rt::Cfg c;
     memset(&c, 0, sizeof c);
@@ -173,6 +176,7 @@ rt::Cfg make_cfg(const rt_ctx* ctx, const rt_params* p) {
     c.n_wl = ctx->n_wl;
     c.mono_index = -1;
     c.log_table = ctx->d_log_table.p;
+    c.quorum = rt::Ablation::scatter_quorum(kScatterQuorum);
     c.escaped_mu = p->escaped_mu;  // a device address here (rt_run substitutes its own buffer for the caller's host array)
     return c;
 }

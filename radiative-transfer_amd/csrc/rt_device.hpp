@@ -116,6 +116,7 @@ struct Cfg {
     int32_t table_base;  // first entry of the current atmosphere's table in rec / alias (several tables back to back)
     const LogTableEntry* log_table;  // kLogTableEntries entries in global memory (copied to LDS per workgroup)
     double* escaped_mu;              // per-photon escape cosines (rt_params.escaped_mu), or null
+    int32_t quorum, pad2_;           // lean kernels: scattering lanes wait until this many have gathered (see walk_kernel)
 };
 
 // Which run flags a kernel has fixed at compile time.  Fixed<...>: loop order, lower boundary, scattering law and the

@@ -315,12 +315,18 @@ __global__ __launch_bounds__(kWalkBlock) void walk_kernel(const Cfg cfg0, const 
                 }
                 cur += n_dead;  // may pass len: the chunk is used up then
             }
-            const bool active = alive || fresh;
-            // FAST: 64 - n_dead lanes scatter, n_new start (a wave of this kernel has 64 lanes)
+            // FAST: the lanes whose photon goes on to scatter wait (in place, masked out) until at least `quorum` of
+            // them have gathered, while the other lanes keep starting photons: in atmospheres where only a few per cent
+            // of the flights end in a scattering, the scattering code then runs once for many lanes instead of in almost
+            // every iteration for one or two.  With nothing left to start they always go.  The decision depends on the
+            // wave's own lane states only, so a chunk's results stay reproducible.
+            const bool go = !FAST || 64u - n_dead >= (uint32_t)cfg.quorum || n_new == 0u;
+            const bool active = (alive && go) || fresh;
+            // FAST: 64 - n_dead lanes hold a photon, n_new start one (a wave of this kernel has 64 lanes)
             if (FAST ? n_dead - n_new == 64u : __builtin_amdgcn_ballot_w64(active) == 0ull) break;
             if (FAST) {
                 n_photons += n_new;
-                n_scatter += 64u - n_dead;
+                n_scatter += go ? 64u - n_dead : 0u;
             }
             int fate = 0;
             if (active) {

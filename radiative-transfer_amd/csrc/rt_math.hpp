@@ -20,6 +20,7 @@ struct Ablation {  // the product's values of the switches the timing experiment
     static constexpr bool kUniform53 = false, kPlainFma = false, kSqrtGeneral = false, kDivGeneral = false, kWaveTrace = false;
     static constexpr int kAbiTag = 0;
     static bool chunk_rule(unsigned&, unsigned&) { return false; }
+    static int scatter_quorum(int product) { return product; }
 };
 }  // namespace rt
 #endif

@@ -10,6 +10,7 @@
 //   -DRT_ABL_DIV_GENERAL       the general fp64 division instead of the unscaled sequence
 //   -DRT_ABL_WAVE_TRACE        per-wave start / last-chunk / end clocks of the last walk launch (tools/wave_trace.py)
 //   RT_AMD_CHUNK=thin,thick    (environment, read at load) chunk lengths for atmospheres below / above tau = 0.5
+//   RT_AMD_QUORUM=n            (environment) scattering lanes a wave gathers before it scatters (0 = never wait)
 #pragma once
 #include <cstdio>
 #include <cstdlib>
@@ -56,6 +57,12 @@ struct Ablation {
         thin = a;
         thick = b;
         return true;
+    }
+    // RT_AMD_QUORUM=n (environment): how many scattering lanes a wave gathers before it runs the scattering code
+    static int scatter_quorum(int product) {
+        const char* e = getenv("RT_AMD_QUORUM");
+        const int v = e ? atoi(e) : -1;
+        return v >= 0 && v <= 64 ? v : product;
     }
 };
 
