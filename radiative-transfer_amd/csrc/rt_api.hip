@@ -425,7 +425,7 @@ int enqueue_sweep(rt_ctx* ctx, const rt_params* p, void* d_slab_sums, void* d_co
         const unsigned long long rows = rt::kQueueRows;
         // worth it from about 8 items per resident wave on; a shorter launch is decided by the balance of its end,
         // which the plain heaviest-first order serves best (measured: -4 % at 5 items per wave, +1.5 % at 10, +3.5 % at 24)
-        if (items >= (unsigned long long)grid * 4 * 8 && items - tail >= rows * 8) {
+        if (items >= (unsigned long long)grid * 4 * rt::Ablation::interleave_min(8) && items - tail >= rows * 8) {
             sw.row_len = (uint32_t)((items - tail) / rows);
             sw.n_interleaved = (uint32_t)(sw.row_len * rows);
         }
@@ -444,9 +444,8 @@ int enqueue_sweep(rt_ctx* ctx, const rt_params* p, void* d_slab_sums, void* d_co
     RT_HIP(rt::launch_walk(cfg, sw, variant, (int)grid, stream, d_next, d_chunk_sums, d_count_copies,
                            d_hist_copies, (double*)d_depth));
     if (ev) RT_HIP(hipEventRecord(ev->b, stream));
-    RT_HIP(rt::launch_slab_reduce(sw, d_chunk_sums, (double*)d_slab_sums, stream));
-    RT_HIP(rt::launch_fold_tallies(d_count_copies, lay.n_copies, na * RT_NCNT, (unsigned long long*)d_counts, stream));
-    RT_HIP(rt::launch_fold_tallies(d_hist_copies, lay.n_copies, na * nmu, (unsigned long long*)d_mu_hist, stream));
+    RT_HIP(rt::launch_finish(sw, d_chunk_sums, (double*)d_slab_sums, d_count_copies, (unsigned long long*)d_counts,
+                             na * RT_NCNT, d_hist_copies, (unsigned long long*)d_mu_hist, na * nmu, stream));
     return RT_OK;
 }
 

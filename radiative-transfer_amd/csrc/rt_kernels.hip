@@ -447,25 +447,35 @@ __global__ void zero_results_kernel(unsigned int* __restrict__ d_next, unsigned 
     for (size_t i = t; i < nb; i += stride) b[i] = 0ull;
 }
 
-// out[i] = sum over the copies of in[c * n + i] (integers: any order gives the same bits).
-__global__ void fold_tallies_kernel(const unsigned long long* __restrict__ in, uint32_t n_copies, size_t n,
-                                    unsigned long long* __restrict__ out) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    unsigned long long s = 0ull;
-    for (uint32_t c = 0; c < n_copies; ++c) s += in[(size_t)c * n + i];
-    out[i] = s;
-}
-
-// One wave per (atmosphere, slab); the slabs of other ranks are set to zero.  An owned slab's chunk partials are added in a fixed
-// shape -- lane l takes the slots l, l + 64, ... in order, then the lanes are combined by the butterfly -- that
-// depends on the slab's chunk count only.  Every slot of the range was written by the walk kernel (a chunk beyond
-// the end of a short last slab holds zeros).
-__global__ __launch_bounds__(64) void slab_reduce_kernel(const Sweep sw, const double* __restrict__ d_chunk_sums,
-                                                         double* __restrict__ d_slab_sums) {
+// What follows the walk, in one launch of 64-thread workgroups.
+//   Workgroups [0, n_atm * n_slabs): one wave per (atmosphere, slab); the slabs of other ranks are set to zero.  An
+//   owned slab's chunk partials are added in a fixed shape -- lane l takes the slots l, l + 64, ... in order, then the
+//   lanes are combined by the butterfly -- that depends on the slab's chunk count only.  Every slot of the range was
+//   written by the walk kernel (a chunk beyond the end of a short last slab holds zeros).
+//   The remaining workgroups fold the copies of the integer tallies (counts, then the escape histogram) into the
+//   caller's arrays: out[i] = sum over the copies of in[c * n + i] (integers: any order gives the same bits).
+__global__ __launch_bounds__(64) void finish_kernel(const Sweep sw, const double* __restrict__ d_chunk_sums,
+                                                    double* __restrict__ d_slab_sums,
+                                                    const unsigned long long* __restrict__ d_count_copies,
+                                                    unsigned long long* __restrict__ d_counts, uint32_t n_counts,
+                                                    const unsigned long long* __restrict__ d_hist_copies,
+                                                    unsigned long long* __restrict__ d_mu_hist, uint32_t n_hist) {
+    const int lane = threadIdx.x;
+    const unsigned int n_reduce = sw.n_atm * sw.n_slabs;
+    if (blockIdx.x >= n_reduce) {
+        const unsigned int i = (blockIdx.x - n_reduce) * 64u + (unsigned int)lane;
+        const bool is_count = i < n_counts;
+        const unsigned int j = is_count ? i : i - n_counts;
+        const unsigned int n = is_count ? n_counts : n_hist;
+        if (j >= n) return;
+        const unsigned long long* in = is_count ? d_count_copies : d_hist_copies;
+        unsigned long long s = 0ull;
+        for (uint32_t c = 0; c < sw.n_copies; ++c) s += in[(size_t)c * n + j];
+        (is_count ? d_counts : d_mu_hist)[j] = s;
+        return;
+    }
     const unsigned int a = blockIdx.x / sw.n_slabs;
     const unsigned int slab = blockIdx.x - a * sw.n_slabs;
-    const int lane = threadIdx.x;
     const PlanEntry plan = sw.plan[a];
     if (slab % sw.world != sw.rank) {
         if (lane < RT_NSUM) d_slab_sums[((size_t)plan.atm * sw.n_slabs + slab) * RT_NSUM + lane] = 0.0;
@@ -736,17 +746,14 @@ hipError_t launch_zero_results(unsigned int* d_next, unsigned long long* d_talli
     return hipGetLastError();
 }
 
-hipError_t launch_fold_tallies(const unsigned long long* d_copies, uint32_t n_copies, size_t n, unsigned long long* d_out,
-                               hipStream_t stream) {
-    if (n == 0) return hipSuccess;
-    fold_tallies_kernel<<<(unsigned int)((n + 255) / 256), 256, 0, stream>>>(d_copies, n_copies, n, d_out);
-    return hipGetLastError();
-}
-
-hipError_t launch_slab_reduce(const Sweep& sw, const double* d_chunk_sums, double* d_slab_sums, hipStream_t stream) {
-    const unsigned int total = sw.n_atm * sw.n_slabs;
-    if (total == 0) return hipSuccess;
-    slab_reduce_kernel<<<total, 64, 0, stream>>>(sw, d_chunk_sums, d_slab_sums);
+hipError_t launch_finish(const Sweep& sw, const double* d_chunk_sums, double* d_slab_sums,
+                         const unsigned long long* d_count_copies, unsigned long long* d_counts, size_t n_counts,
+                         const unsigned long long* d_hist_copies, unsigned long long* d_mu_hist, size_t n_hist,
+                         hipStream_t stream) {
+    const size_t grid = (size_t)sw.n_atm * sw.n_slabs + (n_counts + n_hist + 63) / 64;
+    if (grid == 0 || grid > 0x7fffffffull) return grid ? hipErrorInvalidValue : hipSuccess;
+    finish_kernel<<<(unsigned int)grid, 64, 0, stream>>>(sw, d_chunk_sums, d_slab_sums, d_count_copies, d_counts,
+                                                         (uint32_t)n_counts, d_hist_copies, d_mu_hist, (uint32_t)n_hist);
     return hipGetLastError();
 }
 

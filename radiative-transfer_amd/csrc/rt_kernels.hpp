@@ -76,12 +76,12 @@ hipError_t launch_walk(const Cfg& cfg, const Sweep& sw, WalkVariant v, int grid,
 // *d_next = 0, the tally copies and the depth arrays zeroed (lengths in 64-bit words; d_depth may be null with n_depth = 0)
 hipError_t launch_zero_results(unsigned int* d_next, unsigned long long* d_tallies, size_t n_tallies, double* d_depth,
                                size_t n_depth, hipStream_t stream);
-// d_out[i] = sum over c < n_copies of d_copies[c * n + i]
-hipError_t launch_fold_tallies(const unsigned long long* d_copies, uint32_t n_copies, size_t n, unsigned long long* d_out,
-                               hipStream_t stream);
-
-// writes every slab of every atmosphere: the owned ones from their chunk partials, the others zero
-hipError_t launch_slab_reduce(const Sweep& sw, const double* d_chunk_sums, double* d_slab_sums, hipStream_t stream);
+// after the walk: every slab of every atmosphere written (the owned ones from their chunk partials, the others zero)
+// and the copies of the integer tallies folded into d_counts [n_counts] and d_mu_hist [n_hist]
+hipError_t launch_finish(const Sweep& sw, const double* d_chunk_sums, double* d_slab_sums,
+                         const unsigned long long* d_count_copies, unsigned long long* d_counts, size_t n_counts,
+                         const unsigned long long* d_hist_copies, unsigned long long* d_mu_hist, size_t n_hist,
+                         hipStream_t stream);
 
 hipError_t launch_replay(const Cfg& cfg, double tau, long long n, int max_draws, const double* d_xi,
                          const double* d_lam, const double* d_g, const double* d_albedo, const double* d_scale,

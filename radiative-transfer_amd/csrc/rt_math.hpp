@@ -21,6 +21,7 @@ struct Ablation {  // the product's values of the switches the timing experiment
     static constexpr int kAbiTag = 0;
     static bool chunk_rule(unsigned&, unsigned&) { return false; }
     static int scatter_quorum(int product) { return product; }
+    static int interleave_min(int product) { return product; }
 };
 }  // namespace rt
 #endif

@@ -58,6 +58,12 @@ struct Ablation {
         thick = b;
         return true;
     }
+    // RT_AMD_ILV=n (environment): items per resident wave from which the queue is walked in interleaved rows
+    static int interleave_min(int product) {
+        const char* e = getenv("RT_AMD_ILV");
+        const int v = e ? atoi(e) : -1;
+        return v >= 0 ? v : product;
+    }
     // RT_AMD_QUORUM=n (environment): how many scattering lanes a wave gathers before it runs the scattering code
     static int scatter_quorum(int product) {
         const char* e = getenv("RT_AMD_QUORUM");
