@@ -154,6 +154,61 @@ void run(const char* name, K kern, int waves_per_simd, uint32_t* d_out, unsigned
            ghz, ms * 1e-3 * ghz * 1e9 / n);
 }
 
+// Does an instruction cost less when only part of the wave's lanes are enabled?  The same fp64 fma / 32-bit streams
+// with EXEC restricted to the low 32, 16 and 1 lanes for the duration of the loop.
+#define KERNEL64_EXEC(name, MASK)                                                                     \
+    __global__ __launch_bounds__(256) void name(uint32_t* out, unsigned long long* clk) {             \
+        double a = 1.0 + threadIdx.x * 1e-9, b = 1.1, c = 1.2, d = 1.3;                               \
+        double m = 1.0000001;                                                                         \
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();                                   \
+        const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();                               \
+        if ((MASK >> (threadIdx.x & 63)) & 1ull) {                                                    \
+            for (int it = 0; it < kIters; ++it) {                                                     \
+                asm volatile(REP16("v_fma_f64 %0, %0, %4, %4\n v_fma_f64 %1, %1, %4, %4\n v_fma_f64 %2, %2, %4, %4\n v_fma_f64 %3, %3, %4, %4\n") \
+                             : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(m));                          \
+            }                                                                                         \
+        }                                                                                             \
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime();                                   \
+        const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();                               \
+        out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)(a + b + c + d);                       \
+        if (threadIdx.x == 0 && blockIdx.x == 0) { clk[0] = t1 - t0; clk[1] = r1 - r0; }              \
+    }
+KERNEL64_EXEC(k_fma64_exec32, 0x00000000FFFFFFFFull)
+KERNEL64_EXEC(k_fma64_exec16, 0x000000000000FFFFull)
+KERNEL64_EXEC(k_fma64_exec1, 0x0000000000000001ull)
+KERNEL64_EXEC(k_fma64_exec_hi32, 0xFFFFFFFF00000000ull)
+KERNEL64_EXEC(k_fma64_exec_even, 0x5555555555555555ull)
+KERNEL64_EXEC(k_fma64_exec2, 0x0000000000000003ull)
+KERNEL64_EXEC(k_fma64_exec4, 0x000000000000000Full)
+KERNEL64_EXEC(k_fma64_exec8, 0x00000000000000FFull)
+KERNEL64_EXEC(k_fma64_exec1_lane37, 0x0000002000000000ull)
+KERNEL64_EXEC(k_fma64_exec2_far, 0x0000000100000001ull)
+KERNEL64_EXEC(k_fma64_exec12, 0x0000000000000FFFull)
+KERNEL64_EXEC(k_fma64_exec9, 0x00000000000001FFull)
+KERNEL64_EXEC(k_fma64_exec8_spread, 0x0101010101010101ull)
+KERNEL64_EXEC(k_fma64_exec16_spread, 0x1111111111111111ull)
+KERNEL64_EXEC(k_fma64_exec15, 0x0000000000007FFFull)
+#define KERNEL32_EXEC(name, MASK, INSTR)                                                              \
+    __global__ __launch_bounds__(256) void name(uint32_t* out, unsigned long long* clk) {             \
+        uint32_t a = threadIdx.x, b = threadIdx.x * 3u + 1u, c = threadIdx.x * 5u + 2u, d = 7u;       \
+        uint32_t m = 0xD2511F53u;                                                                     \
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();                                   \
+        const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();                               \
+        if ((MASK >> (threadIdx.x & 63)) & 1ull) {                                                    \
+            for (int it = 0; it < kIters; ++it) {                                                     \
+                asm volatile(REP16(INSTR) : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(m));             \
+            }                                                                                         \
+        }                                                                                             \
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime();                                   \
+        const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();                               \
+        out[blockIdx.x * blockDim.x + threadIdx.x] = a ^ b ^ c ^ d;                                   \
+        if (threadIdx.x == 0 && blockIdx.x == 0) { clk[0] = t1 - t0; clk[1] = r1 - r0; }              \
+    }
+KERNEL32_EXEC(k_mullo_exec4, 0xFull, "v_mul_lo_u32 %0, %0, %4\n v_mul_lo_u32 %1, %1, %4\n v_mul_lo_u32 %2, %2, %4\n v_mul_lo_u32 %3, %3, %4\n")
+KERNEL32_EXEC(k_xor_exec4, 0xFull, "v_xor_b32 %0, %0, %4\n v_xor_b32 %1, %1, %4\n v_xor_b32 %2, %2, %4\n v_xor_b32 %3, %3, %4\n")
+KERNEL32_EXEC(k_fma32_exec4, 0xFull, "v_fma_f32 %0, %0, %4, %4\n v_fma_f32 %1, %1, %4, %4\n v_fma_f32 %2, %2, %4, %4\n v_fma_f32 %3, %3, %4, %4\n")
+KERNEL32_EXEC(k_fma32_exec64, 0xFFFFFFFFFFFFFFFFull, "v_fma_f32 %0, %0, %4, %4\n v_fma_f32 %1, %1, %4, %4\n v_fma_f32 %2, %2, %4, %4\n v_fma_f32 %3, %3, %4, %4\n")
+
 int main() {
     uint32_t* d_out;
     unsigned long long* d_clk;
@@ -170,5 +225,6 @@ int main() {
     run("k_xordep", k_xordep, 4, d_out, d_clk);
     run("k_fma64 (1 wave)", k_fma64, 1, d_out, d_clk);
     run("k_fma64 (2 waves)", k_fma64, 2, d_out, d_clk);
+    RUN(k_fma64_exec32); RUN(k_fma64_exec16); RUN(k_fma64_exec1); RUN(k_fma64_exec_hi32); RUN(k_fma64_exec_even); RUN(k_fma64_exec2); RUN(k_fma64_exec4); RUN(k_fma64_exec8); RUN(k_fma64_exec1_lane37); RUN(k_fma64_exec2_far); RUN(k_fma64_exec12); RUN(k_fma64_exec9); RUN(k_fma64_exec15); RUN(k_fma64_exec8_spread); RUN(k_fma64_exec16_spread); RUN(k_mullo_exec4); RUN(k_xor_exec4); RUN(k_fma32_exec4); RUN(k_fma32_exec64);
     return 0;
 }
