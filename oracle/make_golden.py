@@ -166,7 +166,7 @@ REPLAY_CASES = [
 ]
 
 
-def seeded_reference(order, tau, n, boundary, scatter, seed, lam, g, alb, scale):
+def seeded_reference(order, tau, n, boundary, scatter, seed, lam, g, alb, scale, alpha=0.3):
     if order == "mc":
         mod = ref_loader.load_mc_code()
         mod.monochromatic = lam
@@ -175,6 +175,7 @@ def seeded_reference(order, tau, n, boundary, scatter, seed, lam, g, alb, scale)
         emu, B, E, I, count = mod.RunPhotons(tau, n, boundary, scatter, None, None, grain)
     else:
         mod = ref_loader.load_gray()
+        mod.alpha = alpha  # the gray script reads it as a global (Numpy_random_walk.py:16)
         np.random.seed(seed)
         emu, B, E, I = mod.RunPhotons(tau, n, boundary, alb, scatter, g)
         count = -1
@@ -190,7 +191,10 @@ SEEDED_CASES = [
     ("gray_reflect_hg", "gray", 3.0, 20000, "reflect", "hg", 11, 1.0, 0.5, 0.9, 1.0),
     ("gray_reflect_draine", "gray", 3.0, 20000, "reflect", "draine", 12, 1.0, 0.5, 0.9, 1.0),
     ("gray_reemit_iso", "gray", 10.0, 20000, "reemit", "iso", 13, 1.0, 0.0, 1.0, 1.0),
+    # scatter='draine' with g == 0 and alpha == 0 takes the script's IsoScatter branch (Numpy_random_walk.py:388-391)
+    ("gray_reflect_draine_g0_alpha0", "gray", 2.0, 20000, "reflect", "draine", 14, 1.0, 0.0, 0.9, 1.0),
 ]
+SEEDED_ALPHA = {"gray_reflect_draine_g0_alpha0": 0.0}
 
 
 def main():
@@ -211,9 +215,10 @@ def main():
 
     out = {"names": np.array([c[0] for c in SEEDED_CASES])}
     for (name, order, tau, n, boundary, scatter, seed, lam, g, alb, scale) in SEEDED_CASES:
-        emu, B, E, I, count = seeded_reference(order, tau, n, boundary, scatter, seed, lam, g, alb, scale)
+        alpha = SEEDED_ALPHA.get(name, 0.3)
+        emu, B, E, I, count = seeded_reference(order, tau, n, boundary, scatter, seed, lam, g, alb, scale, alpha)
         p = name + "/"
-        for k, v in dict(order=order, tau=tau, n=n, boundary=boundary, scatter=scatter, seed=seed, lam=lam, g=g,
+        for k, v in dict(order=order, tau=tau, n=n, boundary=boundary, scatter=scatter, seed=seed, lam=lam, g=g, alpha=alpha,
                          albedo=alb, scale=scale, ref_escaped_mu=emu, ref_boundary_momentum=B,
                          ref_escaped_momentum=E, ref_initial_momentum=I, ref_scatter_count=count).items():
             out[p + k] = np.asarray(v)

@@ -92,6 +92,22 @@ def test_draine_phase_function(rt, engine, c_oracle):
     compare(res, ref, rt._abi)
 
 
+def test_draine_with_g_and_alpha_zero_is_isotropic(rt, engine, c_oracle):
+    """scatter='draine' with g == 0 and alpha == 0 takes the gray script's IsoScatter branch (Numpy_random_walk.py:388-391):
+    no rejection loop, the lab-frame cosine assigned directly -- the same photon histories as scatter='iso'."""
+    engine.set_tables([1.0], [0.0], [0.9], [1.0])
+    tau = np.array([0.5, 2.0])
+    kw = dict(order="gray", h=1.0, n_mu_bins=10)
+    res = engine.run(rt.make_params(tau, 8000, scatter="draine", alpha=0.0, **kw))
+    ref = c_oracle.run(c_oracle.make_params(tau, 8000, scatter="draine", alpha=0.0, **kw), [1.0], [0.0], [0.9], [1.0])
+    compare(res, ref, rt._abi)
+    iso = engine.run(rt.make_params(tau, 8000, scatter="iso", **kw))
+    assert np.array_equal(res.counts, iso.counts) and np.array_equal(res.mu_hist, iso.mu_hist)
+    np.testing.assert_allclose(res.sums, iso.sums, rtol=1e-12)
+    # one block per scattering, not a rejection loop: flights + scatterings blocks in all
+    assert res.counts[:, rt._abi.CNT_GUARD].sum() == 0
+
+
 def test_result_independent_of_gpu_count(rt, engine):
     """Walking the slabs as 1, 2, 4 or 8 ranks gives bitwise the same tallies after the slab sum."""
     wl, g, alb, scale, pdf = small_table()

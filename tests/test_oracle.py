@@ -97,7 +97,7 @@ def test_numpy_walk_seeded_matches_reference(name):
     full = lambda v: np.full(n, float(v))
     r = nw.run_photons(float(c["tau"]), full(c["lam"]), full(c["g"]), full(c["albedo"]), full(c["scale"]), np.ones(n),
                        boundary=str(c["boundary"]), scatter=str(c["scatter"]), order=order,
-                       stream=nw.GlobalStream(rs), h=(1 if order == "gray" else nw.H_PLANCK))
+                       stream=nw.GlobalStream(rs), h=(1 if order == "gray" else nw.H_PLANCK), alpha=float(c["alpha"]))
     assert np.array_equal(r["escaped_mu"], c["ref_escaped_mu"])
     assert r["boundary_momentum"] == float(c["ref_boundary_momentum"])
     assert r["escaped_momentum"] == float(c["ref_escaped_momentum"])
