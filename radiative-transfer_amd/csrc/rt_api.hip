@@ -503,6 +503,19 @@ int rt_create(rt_ctx** out, int device_id) {
         }
         ctx->order.resize(kStaticMaxAtm);
         ctx->mu_base.resize(kStaticMaxAtm);
+        // Load the library's device code now (the runtime does that, and allocates for it, at the first launch from a
+        // code object): rt_run_device_static must find nothing left to set up.  The launch clears the queue counter
+        // of the static work array.
+        e = rt::launch_zero_results(reinterpret_cast<unsigned int*>(ctx->static_scratch), nullptr, 0, nullptr, 0, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) {
+            rt_destroy(ctx);
+            return fail(RT_ERR_DEVICE, "first kernel launch: %s", hipGetErrorString(e));
+        }
+        for (int v = 0; v < rt::kWalkVariants; ++v) {
+            ctx->blocks_lds[v] = rt::walk_lds_bytes(10, 0);  // the default histogram; other sizes are queried when they occur
+            ctx->blocks_per_cu[v] = rt::walk_max_blocks_per_cu((rt::WalkVariant)v, ctx->blocks_lds[v]);
+        }
     }
     // logarithm table for the kernels' ln(): c_j = 1 + (j + 1/2)/128, inv_c = fl(1/c_j), l = -ln(inv_c)
     std::vector<rt::LogTableEntry> tab(rt::kLogTableEntries);
