@@ -63,3 +63,37 @@ def test_static_entry_point_refuses_what_does_not_fit(rt):
     b = _run(rt, eng, torch, np.array([1.0]), 1000, static=False)
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
     eng.close()
+
+
+def test_static_entry_point_leaves_device_memory_alone(rt):
+    """Free device memory is the same before and after static sweeps of growing size on a fresh context, while the
+    allocating entry point takes its work memory from the device on its first large call.  (What is compared is the
+    device's free memory, so the test sees allocations by anyone in the process, the runtime included.)"""
+    import torch
+    A = rt._abi
+    eng = rt.Engine(0)
+    eng.set_tables(*_tables())
+    tau, n = np.logspace(-2, 1.5, 40), 2000000
+    dev = torch.device("cuda", 0)
+    slab = torch.zeros(len(tau) * 8 * A.NSUM, dtype=torch.float64, device=dev)
+    counts = torch.zeros(len(tau) * A.NCNT, dtype=torch.int64, device=dev)
+    hist = torch.zeros(len(tau) * 11, dtype=torch.int64, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    # one small call first: the HIP runtime sets up its own pools (kernel arguments, signals) at a process's first launches
+    eng.run_device(rt.make_params(tau[:1], 1000, n_mu_bins=10), slab.data_ptr(), counts.data_ptr(), hist.data_ptr(), None,
+                   stream, static=True)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info(0)[0]
+    for k in (1, 4, 40):   # 1, 4, 40 atmospheres: ever more plan entries and chunk partial sums
+        p = rt.make_params(tau[:k], n, n_mu_bins=10)
+        eng.run_device(p, slab.data_ptr(), counts.data_ptr(), hist.data_ptr(), None, stream, static=True)
+        torch.cuda.synchronize()
+        assert torch.cuda.mem_get_info(0)[0] == free0
+    # the allocating entry point on a sweep whose work memory is tens of MB (40 atmospheres x 2e7 photons: 97 920 chunks)
+    big = rt.make_params(tau, 20000000, n_mu_bins=10)
+    eng.run_device(big, slab.data_ptr(), counts.data_ptr(), hist.data_ptr(), None, stream, static=False)
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info(0)[0] < free0
+    eng.run_device(big, slab.data_ptr(), counts.data_ptr(), hist.data_ptr(), None, stream, static=True)   # fits the array: 8.9 MB
+    torch.cuda.synchronize()
+    eng.close()
