@@ -26,9 +26,9 @@ constexpr int kWavesPerBlock = kWalkBlock / 64;
 #ifdef RT_ABLATION
 // Experiment builds only (tools/wave_trace.py): per wave of the last walk launch, 100 MHz clock at its first queue pop,
 // at the start of its last chunk and at its end, and the number of chunks it walked.
-__device__ unsigned long long g_wave_trace[4 * 8192];
+__device__ unsigned long long g_wave_trace[8 * 8192];
 extern "C" int rt_debug_wave_trace(unsigned long long* out, int n_waves) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_trace), sizeof(unsigned long long) * 4 * (size_t)n_waves);
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_trace), sizeof(unsigned long long) * 8 * (size_t)n_waves);
 }
 #else
 __device__ unsigned long long g_wave_trace[1];  // never written: Ablation::kWaveTrace is false
@@ -242,6 +242,7 @@ __global__ __launch_bounds__(kWalkBlock) void walk_kernel(const Cfg cfg0, const 
     }
 
     unsigned long long t_begin = 0ull, t_last = 0ull, n_done = 0ull;
+    unsigned long long n_iter = 0ull, n_drain = 0ull, n_drain_few = 0ull, n_lanes = 0ull;  // experiment builds only
     if constexpr (Ablation::kWaveTrace) t_begin = t_last = wall_clock64();
     WorkItem it;
     while (pop_item(sw, d_next, lane, it)) {
@@ -327,6 +328,15 @@ __global__ __launch_bounds__(kWalkBlock) void walk_kernel(const Cfg cfg0, const 
             if (FAST) {
                 n_photons += n_new;
                 n_scatter += go ? 64u - n_dead : 0u;
+            }
+            if constexpr (Ablation::kWaveTrace && FAST) {  // iterations, those after the chunk ran out, lanes at work
+                const uint32_t busy = n_new + (go ? 64u - n_dead : 0u);
+                ++n_iter;
+                n_lanes += busy;
+                if (cur >= len) {
+                    ++n_drain;
+                    if (busy <= 4u) ++n_drain_few;
+                }
             }
             int fate = 0;
             if (active) {
@@ -428,11 +438,15 @@ __global__ __launch_bounds__(kWalkBlock) void walk_kernel(const Cfg cfg0, const 
     }
     if constexpr (Ablation::kWaveTrace) {
         if (lane == 0) {
-            unsigned long long* t = g_wave_trace + 4 * (size_t)(blockIdx.x * kWavesPerBlock + wave);
+            unsigned long long* t = g_wave_trace + 8 * (size_t)(blockIdx.x * kWavesPerBlock + wave);
             t[0] = t_begin;
             t[1] = t_last;  // start of this wave's last chunk
             t[2] = wall_clock64();
             t[3] = n_done;
+            t[4] = n_iter;
+            t[5] = n_drain;      // iterations after the chunk's last id was handed out
+            t[6] = n_drain_few;  // ... with at most 4 lanes at work
+            t[7] = n_lanes;      // lanes at work summed over the iterations
         }
     }
 }

@@ -26,7 +26,7 @@ eng.kernel_time(reset=True)
 eng.run(prm)
 ms = eng.kernel_time()[0]
 nw = 5120
-buf = np.zeros((nw, 4), dtype=np.uint64)
+buf = np.zeros((nw, 8), dtype=np.uint64)
 lib = eng._lib
 rc = lib.rt_debug_wave_trace(buf.ctypes.data_as(C.POINTER(C.c_uint64)), nw)
 assert rc == 0
@@ -44,6 +44,9 @@ print("wave end   (ms)  " + "  ".join(f"p{p} {v:.3f}" for p, v in zip(q, np.perc
 print("last chunk (ms)  " + "  ".join(f"p{p} {v:.3f}" for p, v in zip(q, np.percentile(end - last, q))))
 idle = (span - end).sum() / (span * len(t))
 print(f"idle wave-time after a wave's end, share of waves x span: {idle:.4f}")
+it, drain, few, lanes = (t[:, k].sum() for k in (4, 5, 6, 7))
+print(f"loop iterations {it:.3e}; after a chunk's last id was handed out {drain / it:.4f} of them, with at most 4 lanes at work "
+      f"{few / it:.4f}; mean lanes at work per iteration {lanes / it:.2f}")
 # how full is the machine over time: waves still running at time x
 for x in np.linspace(0.8, 1.0, 11):
     print(f"  t = {x:.2f} span: {np.mean(end > x * span):.3f} of the waves still running")
