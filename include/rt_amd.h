@@ -231,26 +231,29 @@ int rt_run(rt_ctx* ctx, const rt_params* p, rt_tallies* out);
 /* Same sweep, results left on the device for a collective:
  * d_slab_sums  [n_atm][n_slabs][RT_NSUM] doubles, d_counts [n_atm][RT_NCNT] u64,
  * d_mu_hist [n_atm][n_mu_bins+1] u64, d_depth [2][n_atm][n_depth_bins] doubles (may be NULL when
- * n_depth_bins == 0).  Buffers are overwritten (zeroed, then filled with this rank's share). The work
+ * n_depth_bins == 0).  Buffers are overwritten (every entry: this rank's share, zeros for the slabs of other ranks). The work
  * is enqueued on `stream` (a hipStream_t passed as void*; NULL = default stream) and NOT synchronised.
- * A context owns one set of device work buffers (work queue, chunk partial sums): successive calls on one
+ * A context owns one block of device work memory (plan, work queue, tally copies, chunk partial sums; it grows on
+ * demand, so a call may allocate): successive calls on one
  * context must go to the same stream, or the caller orders them itself (event or synchronise) -- two
  * sweeps of one context in flight on different streams race.  Use one context per concurrent stream. */
 int rt_run_device(rt_ctx* ctx, const rt_params* p, void* d_slab_sums, void* d_counts, void* d_mu_hist,
                   void* d_depth, void* stream);
 
-/* The same sweep for callers that cannot allocate: code under HIP graph capture, tight serving loops, harnesses
- * that forbid hipMalloc.  No counterpart in the reference.  Same arguments and results as rt_run_device, bit for
- * bit, but the work memory (work queue, plan, chunk partial sums) is a static device array of 32 MiB that the
- * library holds on every GPU it runs on from load to process exit, and the call itself allocates nothing on the
- * device or the host and frees nothing; its kernel is not timed (rt_kernel_time does not see it).
+/* The same sweep for callers that cannot allocate: tight serving loops, harnesses that forbid hipMalloc, code that
+ * must not disturb the allocator (e.g. while another stream is being captured into a HIP graph).  No counterpart in
+ * the reference.  Same arguments and results as rt_run_device, bit for bit, but the work memory (work queue, plan,
+ * tally copies, chunk partial sums) is a static device array of 32 MiB that the library holds on every GPU it runs on
+ * from load to process exit, and the call itself allocates nothing on the device or the host and frees nothing; its
+ * kernel is not timed (rt_kernel_time does not see it).  (The call is not itself capturable: it records an event
+ * after the plan upload and waits for the previous call's before it reuses the staging buffer.)
  * Limits (RT_ERR_LIMIT beyond them, before anything is enqueued): n_atm <= 4096, and the work memory within the
  * array: 60 * n_atm bytes of plan, up to 8 MiB of tally copies (8 * n_atm * (RT_NCNT + n_mu_bins + 1) bytes each, as
  * many as fit, at most 64) and 80 bytes per chunk of this rank's slabs (a chunk is 8192 photon ids for slabs of at
  * least 250 000 ids, shorter below) <= 33554432 bytes in all -- the headline sweep (100 atmospheres x 2e7 photons on
- * one GPU: 244 800 chunks) needs 21 MB of it.  rt_set_tables must have been called before (that call allocates).  All contexts of one GPU share the array: two static sweeps in flight on one GPU at the same time,
- * on whatever streams or contexts, race; successive calls on one stream are ordered and need no clearing by the
- * caller. */
+ * one GPU: 244 800 chunks) needs 21 MB of it.  rt_set_tables must have been called before (that call allocates).
+ * All contexts of one GPU share the array: two static sweeps in flight on one GPU at the same time, on whatever
+ * streams or contexts, race; successive calls on one stream are ordered and need no clearing by the caller. */
 int rt_run_device_static(rt_ctx* ctx, const rt_params* p, void* d_slab_sums, void* d_counts, void* d_mu_hist,
                          void* d_depth, void* stream);
 
