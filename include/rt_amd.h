@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 6
+#define RT_ABI_VERSION 7
 
 typedef enum rt_status {
     RT_OK = 0,
@@ -331,6 +331,25 @@ enum rt_shell_status {
     RT_SHELL_STEP_LIMIT = 3   /* max_steps used up */
 };
 
+/* gal_data as ODEs reads it when the reference's includeWholeGalaxy flag is set (MC code.py:919-920, 940-941): the
+ * light and the gravity of every region of the galaxy as seen from the region being integrated.  The reference
+ * prepares the two per-view columns for one region_ID at a time (commented set-up, MC code.py:1682-1683); here
+ * n_views such views are handed over together and integrated region i uses view view_of_region[i].  The formulas
+ * are taken as written, units included: sin(arctan(r / dist_to_ref / cm_pc)) weights both sums, the gravity sum
+ * divides by (dist_to_ref / cm_pc)^2 + r^2 and leaves out row self_row[i] (gal_data.ID != region_ID), the light
+ * sum runs over all rows (the region's own row has dist_to_ref = 0: weight 1).  All pointers are host arrays. */
+typedef struct rt_shell_galaxy {
+    int32_t n_gal;                 /* rows of gal_data (>= 1) */
+    int32_t n_views;               /* >= 1 */
+    double cm_pc;                  /* constants.py:2 */
+    double ratio_rp_lambda_rp;     /* GetRatios(...)[2] at time_slice (MC code.py:1678) */
+    const double* lha_ratio_f;     /* [n_views][n_gal] gal_data.LHa_ratio_f */
+    const double* dist_to_ref;     /* [n_views][n_gal] gal_data.dist_to_ref, pc, >= 0 */
+    const double* mass_tot;        /* [n_gal] gal_data.Mass_tot, g */
+    const int32_t* view_of_region; /* [regions->n] in [0, n_views) */
+    const int32_t* self_row;       /* [regions->n] in [-1, n_gal): the region's own row of gal_data, -1 = none */
+} rt_shell_galaxy;
+
 /* What ODEs reads besides the region (MC code.py:905-955): the curve MC_data (GetMC, :843-863), the
  * luminosity of the population per age (L_ratio, :917) and the physical constants.  All pointers are host
  * arrays; grids ascending. */
@@ -350,6 +369,7 @@ typedef struct rt_shell_model {
     const double* l_age;           /* [n_lage] ages of l_val / ratio_val */
     const double* l_val;           /* [n_lage] summed luminosity per age (needed if aging) */
     const double* ratio_val;       /* [n_lage] GetRatios' ratio_rp_lambda_rp per age (needed if tau_cutoff > 0) */
+    const rt_shell_galaxy* galaxy; /* includeWholeGalaxy (MC code.py:118): NULL = off, the reference's setting */
 } rt_shell_model;
 
 /* regionData of GetRegionVelocity (MC code.py:1438-1457), one entry per region, cgs units. */

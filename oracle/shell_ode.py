@@ -8,8 +8,9 @@ Restates, one scalar point at a time and with the reference's own expressions:
     GetRatios    MC code.py:1130-1152   (ratio_rp_lambda_rp, always the np.interp branch: `time in
                                           L_Edd_DF.time` tests the time MODULE and is never true)
     GetMC        MC code.py:843-863
-    ODEs         MC code.py:905-955     (includeWholeGalaxy off)
-Pinned by tests/golden/shell.npz, which holds the reference's own outputs (oracle/make_golden_shell.py).
+    ODEs         MC code.py:905-955     (with and without includeWholeGalaxy)
+Pinned by tests/golden/shell.npz and shell_galaxy.npz, which hold the reference's own outputs
+(oracle/make_golden_shell.py, oracle/make_golden_shell_galaxy.py).
 Where the reference's interpn raises (points outside the curve's grid) this restatement clamps, as the
 device code does; the golden file has NaN there and the tests skip those points.
 """
@@ -43,6 +44,15 @@ class Region:
         self.h_g_i = float(z["h_g"]) * CM_PC
 
 
+class Galaxy:
+    """gal_data as ODEs reads it with includeWholeGalaxy (MC code.py:919-920, 940-941), seen from one region."""
+
+    def __init__(self, lha_ratio_f, dist_to_ref, mass_tot, self_row, ratio_rp_lambda_rp):
+        self.lha_ratio_f, self.dist_to_ref, self.mass_tot = (np.asarray(x, float) for x in (lha_ratio_f, dist_to_ref, mass_tot))
+        self.others = np.arange(len(self.mass_tot)) != self_row  # gal_data.ID != region_ID
+        self.ratio = float(ratio_rp_lambda_rp)
+
+
 def get_tau_ir(r, l_bol, sigma_g):
     t_eff = (l_bol / (4 * np.pi * r ** 2 * SIGMA_SB)) ** 0.25
     tau_r = 2.4 * 10 ** -4 * t_eff ** 2 * sigma_g
@@ -72,10 +82,14 @@ def get_mc(m, tau, new_time):
                  + y0 * y1 * vals[i + 1, k + 1])
 
 
-def rhs(r, X, m, q):
+def rhs(r, X, m, q, gal=None):
     v, t = X
     new_time = np.log10(t)
     l_bol = q.L_Bol
+    if gal is not None:
+        with np.errstate(divide="ignore"):
+            toward = np.sin(np.arctan(r / gal.dist_to_ref / CM_PC))  # the region itself: dist 0 -> 1
+        l_bol = q.L_Bol * (1 - np.exp(-q.tau_i * gal.ratio) + np.sum(gal.lha_ratio_f * toward))
     tau_new = (q.h_g_i / r) ** 2 * q.tau_i
     log_age = m.time_slice
     if m.aging:
@@ -84,17 +98,20 @@ def rhs(r, X, m, q):
     momentum = get_mc(m, q.tau_i if m.static_momentum else tau_new, log_age) + get_tau_ir(r, l_bol, (q.h_g_i / r) ** 2 * q.Sigma_g)
     mass = (q.M_g + q.M_CO_Hi * (min(r, m.h_hi_cm) / q.h_g_i) ** 3 + q.M_new + q.M_old * (min(r, q.H_old) / q.h_g_i) ** 3)
     dvdr = (-G_NEWTON * mass / r ** 2 + momentum * l_bol / (C_LIGHT * q.M_g)) / v
+    if gal is not None:
+        o = gal.others
+        dvdr -= G_NEWTON * np.sum(gal.mass_tot[o] / ((gal.dist_to_ref[o] / CM_PC) ** 2 + r ** 2) * toward[o]) / v
     dtdr = 1 / (v * 31556952)
     if r > 10000 * CM_PC:
         dvdr = -np.inf
     return dvdr, dtdr
 
 
-def integrate_region(m, q, r_end, v_0, t_0, n_out, rtol=1e-10, max_step=CM_PC):
+def integrate_region(m, q, r_end, v_0, t_0, n_out, rtol=1e-10, max_step=CM_PC, gal=None):
     """v and t at r0 + (k+1)/n_out (r_end - r0); NaN beyond what could be integrated.  Also the last radius."""
     r0 = q.h_g_i
     grid = r0 + (np.arange(n_out) + 1.0) / n_out * (r_end - r0)
-    sol = integrate.solve_ivp(rhs, [r0, r_end], [v_0, t_0], args=(m, q), method="DOP853", rtol=rtol, atol=[1e-7, 1e-7],
+    sol = integrate.solve_ivp(rhs, [r0, r_end], [v_0, t_0], args=(m, q, gal), method="DOP853", rtol=rtol, atol=[1e-7, 1e-7],
                               max_step=max_step, dense_output=True)
     v = np.full(n_out, np.nan)
     t = np.full(n_out, np.nan)

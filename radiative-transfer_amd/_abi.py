@@ -11,7 +11,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "csrc", "librt_amd.so")
 
-RT_ABI_VERSION = 6
+RT_ABI_VERSION = 7
 
 BOUNDARY = {"reflect": 0, "absorb": 1, "reemit": 2}
 SCATTER = {"hg": 0, "iso": 1, "draine": 2, "draine_exact": 3}
@@ -63,11 +63,18 @@ class RtGrainTables(C.Structure):
                 ("lum", C.c_double)]
 
 
+class RtShellGalaxy(C.Structure):
+    _fields_ = [("n_gal", C.c_int32), ("n_views", C.c_int32), ("cm_pc", C.c_double), ("ratio_rp_lambda_rp", C.c_double)] \
+             + [(n, c_double_p) for n in ("lha_ratio_f", "dist_to_ref", "mass_tot")] \
+             + [("view_of_region", C.POINTER(C.c_int32)), ("self_row", C.POINTER(C.c_int32))]
+
+
 class RtShellModel(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("aging", "static_momentum", "n_tau", "n_age", "n_lage", "pad_")] \
              + [(n, C.c_double) for n in ("G", "c", "sigma_sb", "year_s", "h_hi_cm", "r_escape", "time_slice",
                                           "tau_cutoff", "l_norm")] \
-             + [(n, c_double_p) for n in ("mc_tau", "mc_age", "mc_val", "l_age", "l_val", "ratio_val")]
+             + [(n, c_double_p) for n in ("mc_tau", "mc_age", "mc_val", "l_age", "l_val", "ratio_val")] \
+             + [("galaxy", C.POINTER(RtShellGalaxy))]
 
 
 SHELL_REGION_FIELDS = ("m_g", "m_new", "m_old", "m_co_hi", "h_old", "h_g_i", "tau_i", "l_bol", "sigma_g", "r_end")

@@ -876,6 +876,8 @@ namespace {
 // Host arrays of the model and the regions packed into one device buffer; fills device-pointer copies.
 struct ShellUpload {
     DevBuf<double> buf;
+    DevBuf<int32_t> ibuf;  // view_of_region, self_row
+    std::vector<int32_t> ihost;
     std::vector<double> host;
     std::vector<size_t> off;
     size_t add(const double* p, size_t n) {
@@ -902,6 +904,26 @@ int check_shell_model(const rt_shell_model* m) {
     return RT_OK;
 }
 
+// The rows of gal_data and the views onto them (model->galaxy); the per-region arrays must name existing views / rows.
+int check_shell_galaxy(const rt_shell_galaxy* g, int n_regions) {
+    if (!g) return RT_OK;
+    if (g->n_gal < 1 || g->n_views < 1) return fail(RT_ERR_INVALID, "galaxy: n_gal and n_views must be >= 1");
+    if ((long long)g->n_gal * g->n_views > (1ll << 28)) return fail(RT_ERR_LIMIT, "galaxy: n_views * n_gal beyond 2^28");
+    if (!g->lha_ratio_f || !g->dist_to_ref || !g->mass_tot) return fail(RT_ERR_INVALID, "galaxy: a column is NULL");
+    if (!(g->cm_pc > 0.0)) return fail(RT_ERR_INVALID, "galaxy: cm_pc must be positive");
+    if (n_regions > 0 && (!g->view_of_region || !g->self_row)) return fail(RT_ERR_INVALID, "galaxy: view_of_region / self_row is NULL");
+    for (int i = 0; i < n_regions; ++i) {
+        if (g->view_of_region[i] < 0 || g->view_of_region[i] >= g->n_views)
+            return fail(RT_ERR_INVALID, "galaxy: region %d names view %d of %d", i, g->view_of_region[i], g->n_views);
+        if (g->self_row[i] < -1 || g->self_row[i] >= g->n_gal)
+            return fail(RT_ERR_INVALID, "galaxy: region %d names row %d of %d", i, g->self_row[i], g->n_gal);
+    }
+    const size_t cells = (size_t)g->n_gal * (size_t)g->n_views;
+    for (size_t k = 0; k < cells; ++k)
+        if (g->dist_to_ref[k] < 0.0) return fail(RT_ERR_INVALID, "galaxy: dist_to_ref[%zu] is negative", k);
+    return RT_OK;
+}
+
 int check_shell_regions(const rt_shell_regions* rg) {
     if (!rg) return fail(RT_ERR_INVALID, "regions is NULL");
     if (rg->n < 0) return fail(RT_ERR_INVALID, "negative region count");
@@ -915,10 +937,14 @@ int check_shell_regions(const rt_shell_regions* rg) {
     return RT_OK;
 }
 
-// Packs model + regions, uploads, and returns device-pointer views.
+// Packs model + regions (+ the galaxy's rows), uploads, and returns device-pointer views; *dgal_out is &dg or nullptr.
 hipError_t upload_shell(rt_ctx* ctx, const rt_shell_model* m, const rt_shell_regions* rg, ShellUpload& up,
-                        rt::ShellModel& dm, rt::ShellRegions& dr) {
+                        rt::ShellModel& dm, rt::ShellRegions& dr, rt::ShellGalaxy& dg, const rt::ShellGalaxy** dgal_out) {
     const size_t n = (size_t)rg->n;
+    const rt_shell_galaxy* gal = m->galaxy;
+    const size_t cells = gal ? (size_t)gal->n_gal * (size_t)gal->n_views : 0;
+    const size_t o_lha = up.add(gal ? gal->lha_ratio_f : nullptr, cells), o_dist = up.add(gal ? gal->dist_to_ref : nullptr, cells);
+    const size_t o_mass = up.add(gal ? gal->mass_tot : nullptr, gal ? (size_t)gal->n_gal : 0);
     const size_t o_tau = up.add(m->mc_tau, (size_t)m->n_tau), o_age = up.add(m->mc_age, (size_t)m->n_age);
     const size_t o_val = up.add(m->mc_val, (size_t)m->n_tau * (size_t)m->n_age);
     const size_t nl = (m->aging || m->tau_cutoff > 0.0) ? (size_t)m->n_lage : 0;
@@ -933,7 +959,24 @@ hipError_t upload_shell(rt_ctx* ctx, const rt_shell_model* m, const rt_shell_reg
     if (e != hipSuccess) return e;
     e = hipMemcpyAsync(up.buf.p, up.host.data(), sizeof(double) * up.host.size(), hipMemcpyHostToDevice, ctx->stream);
     if (e != hipSuccess) return e;
+    *dgal_out = nullptr;
+    if (gal) {
+        up.ihost.assign(gal->view_of_region, gal->view_of_region + n);
+        up.ihost.insert(up.ihost.end(), gal->self_row, gal->self_row + n);
+        e = up.ibuf.reserve(2 * n);
+        if (e != hipSuccess) return e;
+        e = hipMemcpyAsync(up.ibuf.p, up.ihost.data(), sizeof(int32_t) * 2 * n, hipMemcpyHostToDevice, ctx->stream);
+        if (e != hipSuccess) return e;
+        dg = *gal;
+        dg.lha_ratio_f = up.buf.p + o_lha;
+        dg.dist_to_ref = up.buf.p + o_dist;
+        dg.mass_tot = up.buf.p + o_mass;
+        dg.view_of_region = up.ibuf.p;
+        dg.self_row = up.ibuf.p + n;
+        *dgal_out = &dg;
+    }
     dm = *m;
+    dm.galaxy = nullptr;  // a host address: the kernels get the galaxy as an argument of its own
     dm.mc_tau = up.buf.p + o_tau;
     dm.mc_age = up.buf.p + o_age;
     dm.mc_val = up.buf.p + o_val;
@@ -955,6 +998,7 @@ int rt_shell_rhs(rt_ctx* ctx, const rt_shell_model* model, const rt_shell_region
     if (!ctx) return fail(RT_ERR_INVALID, "ctx is NULL");
     int rc = check_shell_model(model);
     if (rc == RT_OK) rc = check_shell_regions(regions);
+    if (rc == RT_OK) rc = check_shell_galaxy(model->galaxy, regions->n);
     if (rc != RT_OK) return rc;
     if (n < 0 || (n > 0 && (!region || !r || !v || !t || !dvdr || !dtdr))) return fail(RT_ERR_INVALID, "bad argument");
     if (n == 0) return RT_OK;
@@ -964,9 +1008,11 @@ int rt_shell_rhs(rt_ctx* ctx, const rt_shell_model* model, const rt_shell_region
     ShellUpload up;
     rt::ShellModel dm;
     rt::ShellRegions dr;
+    rt::ShellGalaxy dg;
+    const rt::ShellGalaxy* dgal = nullptr;
     DevBuf<double> pts;
     DevBuf<int32_t> idx;
-    hipError_t e = upload_shell(ctx, model, regions, up, dm, dr);
+    hipError_t e = upload_shell(ctx, model, regions, up, dm, dr, dg, &dgal);
     if (e == hipSuccess) e = pts.reserve(5 * (size_t)n);
     if (e == hipSuccess) e = idx.reserve((size_t)n);
     const double* in[3] = {r, v, t};
@@ -974,12 +1020,13 @@ int rt_shell_rhs(rt_ctx* ctx, const rt_shell_model* model, const rt_shell_region
         e = hipMemcpyAsync(pts.p + (size_t)k * n, in[k], sizeof(double) * (size_t)n, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(idx.p, region, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess)
-        e = rt::launch_shell_rhs(dm, dr, n, idx.p, pts.p, pts.p + n, pts.p + 2 * (size_t)n, pts.p + 3 * (size_t)n,
+        e = rt::launch_shell_rhs(dm, dr, dgal, n, idx.p, pts.p, pts.p + n, pts.p + 2 * (size_t)n, pts.p + 3 * (size_t)n,
                                  pts.p + 4 * (size_t)n, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(dvdr, pts.p + 3 * (size_t)n, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(dtdr, pts.p + 4 * (size_t)n, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     up.buf.release();
+    up.ibuf.release();
     pts.release();
     idx.release();
     if (e != hipSuccess) return fail(RT_ERR_DEVICE, "shell right-hand side failed: %s", hipGetErrorString(e));
@@ -991,6 +1038,7 @@ int rt_shell_velocity(rt_ctx* ctx, const rt_shell_model* model, const rt_shell_r
     if (!ctx || !control || !out) return fail(RT_ERR_INVALID, "NULL argument");
     int rc = check_shell_model(model);
     if (rc == RT_OK) rc = check_shell_regions(regions);
+    if (rc == RT_OK) rc = check_shell_galaxy(model->galaxy, regions->n);
     if (rc != RT_OK) return rc;
     if (!(control->v0 > 0.0) || !(control->t0 > 0.0) || !(control->rtol > 0.0) || !(control->max_step > 0.0) ||
         control->atol_v < 0.0 || control->atol_t < 0.0 || control->n_out < 0 || control->max_steps < 1)
@@ -1004,9 +1052,11 @@ int rt_shell_velocity(rt_ctx* ctx, const rt_shell_model* model, const rt_shell_r
     ShellUpload up;
     rt::ShellModel dm;
     rt::ShellRegions dr;
+    rt::ShellGalaxy dg;
+    const rt::ShellGalaxy* dgal = nullptr;
     DevBuf<double> res;
     DevBuf<int32_t> ires;
-    hipError_t e = upload_shell(ctx, model, regions, up, dm, dr);
+    hipError_t e = upload_shell(ctx, model, regions, up, dm, dr, dg, &dgal);
     if (e == hipSuccess) e = res.reserve(6 * n + 2 * n * no + 1);
     if (e == hipSuccess) e = ires.reserve(2 * n);
     rt::ShellResult dout;
@@ -1020,7 +1070,7 @@ int rt_shell_velocity(rt_ctx* ctx, const rt_shell_model* model, const rt_shell_r
     dout.t_out = res.p + 6 * n + n * no;
     dout.status = ires.p;
     dout.n_steps = ires.p + n;
-    if (e == hipSuccess) e = rt::launch_shell_ode(dm, dr, *control, dout, ctx->stream);
+    if (e == hipSuccess) e = rt::launch_shell_ode(dm, dr, dgal, *control, dout, ctx->stream);
     double* hd[6] = {out->v_max, out->r_vmax, out->t_vmax, out->r_last, out->v_last, out->t_last};
     for (int k = 0; k < 6 && e == hipSuccess; ++k)
         e = hipMemcpyAsync(hd[k], res.p + (size_t)k * n, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream);
@@ -1030,6 +1080,7 @@ int rt_shell_velocity(rt_ctx* ctx, const rt_shell_model* model, const rt_shell_r
     if (e == hipSuccess) e = hipMemcpyAsync(out->n_steps, ires.p + n, sizeof(int32_t) * n, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     up.buf.release();
+    up.ibuf.release();
     res.release();
     ires.release();
     if (e != hipSuccess) return fail(RT_ERR_DEVICE, "shell integration failed: %s", hipGetErrorString(e));

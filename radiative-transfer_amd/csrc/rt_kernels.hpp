@@ -124,11 +124,15 @@ typedef rt_shell_model ShellModel;
 typedef rt_shell_regions ShellRegions;
 typedef rt_shell_control ShellControl;
 typedef rt_shell_result ShellResult;
+typedef rt_shell_galaxy ShellGalaxy;
 
-hipError_t launch_shell_rhs(const ShellModel& m, const ShellRegions& rg, int n, const int32_t* d_region,
-                            const double* d_r, const double* d_v, const double* d_t, double* d_dvdr, double* d_dtdr,
-                            hipStream_t stream);
-hipError_t launch_shell_ode(const ShellModel& m, const ShellRegions& rg, const ShellControl& ct, const ShellResult& out,
-                            hipStream_t stream);
+// gal = nullptr: one region (or point) per lane.  With the galaxy's other regions (gal != nullptr, device pointers;
+// the model's own `galaxy` field is not read on the device) one wave serves a region and its lanes share the sums
+// over gal_data's rows.
+hipError_t launch_shell_rhs(const ShellModel& m, const ShellRegions& rg, const ShellGalaxy* gal, int n,
+                            const int32_t* d_region, const double* d_r, const double* d_v, const double* d_t,
+                            double* d_dvdr, double* d_dtdr, hipStream_t stream);
+hipError_t launch_shell_ode(const ShellModel& m, const ShellRegions& rg, const ShellGalaxy* gal, const ShellControl& ct,
+                            const ShellResult& out, hipStream_t stream);
 
 }  // namespace rt

@@ -4,11 +4,14 @@
 // Reference semantics (file:line into the reference checkout):
 //   get_tau_IR          MC code.py:781-807    infrared optical depth of the shell
 //   GetMC               MC code.py:843-863    momentum transfer function at (tau, log age): the curve runMC wrote
-//   ODEs                MC code.py:905-955    dv/dr and dt/dr of the spherical shell
+//   ODEs                MC code.py:905-955    dv/dr and dt/dr of the spherical shell, with or without the light and
+//                                             gravity of the galaxy's other regions (includeWholeGalaxy, :919-920, :940-941)
 //   GetRegionVelocity   MC code.py:1433-1472  integration from h_g to 100 H_old, v(h_g) = v_0, t(h_g) = t_0
 // The reference integrates one region at a time with scipy's Radau (max_step = 1 pc); here an embedded
 // Dormand-Prince 5(4) pair with the same step cap runs one region per lane.  The system is not stiff;
 // what makes it delicate is dv/dr ~ 1/v when a shell stalls, which step-size control handles.
+// With the galaxy's other regions every right-hand side holds two sums over all rows of gal_data: then one
+// wave integrates one region, all 64 lanes carry the same state and share the sums.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -102,10 +105,46 @@ __device__ __forceinline__ Region load_region(const ShellRegions& rg, int i) {
             rg.sigma_g[i]};
 }
 
-// ODEs, MC code.py:913-955 (includeWholeGalaxy off)
-__device__ void rhs(const ShellModel& m, const Region& q, double r, double v, double t, double& dvdr, double& dtdr) {
+// sin(arctan(x)) for x >= 0 or NaN: x / sqrt(1 + x^2), which rounds to 1 from x = 2^27 on (x = +inf: dist_to_ref = 0)
+__device__ __forceinline__ double sin_of_arctan(double x) { return x >= 134217728.0 ? 1.0 : x / sqrt(1.0 + x * x); }
+
+// Sum over the wave; every lane returns the same bits (each butterfly step adds the same two numbers on both sides).
+__device__ __forceinline__ double wave_sum(double a) {
+    for (int s = 32; s >= 1; s >>= 1) a += __shfl_xor(a, s, 64);
+    return a;
+}
+
+// The two sums of ODEs over gal_data (MC code.py:920, :941), formulas and units as written there.  Called by all 64
+// lanes of a wave with the same arguments; lane l takes rows l, l + 64, ...
+struct GalaxySums {
+    double light;    // sum over all rows of LHa_ratio_f * sin(arctan(r / dist_to_ref / cm_pc))
+    double gravity;  // sum over rows != self of Mass_tot / ((dist_to_ref / cm_pc)^2 + r^2) * sin(arctan(...))
+};
+__device__ GalaxySums galaxy_sums(const ShellGalaxy& g, int view, int self, double r) {
+    const double* __restrict__ lha = g.lha_ratio_f + (size_t)view * g.n_gal;
+    const double* __restrict__ dist = g.dist_to_ref + (size_t)view * g.n_gal;
+    double light = 0.0, gravity = 0.0;
+    for (int j = (int)(threadIdx.x & 63u); j < g.n_gal; j += 64) {
+        const double d = dist[j];
+        const double toward = sin_of_arctan(r / d / g.cm_pc);
+        light += lha[j] * toward;
+        const double dd = d / g.cm_pc;
+        if (j != self) gravity += g.mass_tot[j] / (dd * dd + r * r) * toward;
+    }
+    return {wave_sum(light), wave_sum(gravity)};
+}
+
+// ODEs, MC code.py:913-955.  GAL: includeWholeGalaxy, `view` / `self` are the region's entries of view_of_region / self_row.
+template <bool GAL>
+__device__ void rhs(const ShellModel& m, const ShellGalaxy& g, int view, int self, const Region& q, double r, double v,
+                    double t, double& dvdr, double& dtdr) {
     const double new_time = log10(t);
     double l_bol = q.l_bol;
+    GalaxySums gs = {0.0, 0.0};
+    if constexpr (GAL) {
+        gs = galaxy_sums(g, view, self, r);
+        l_bol = q.l_bol * (1.0 - exp(-q.tau_i * g.ratio_rp_lambda_rp) + gs.light);
+    }
     const double s = q.h_g_i / r;
     const double tau_new = (s * s) * q.tau_i;
     const double sigma_now = (s * s) * q.sigma_g;
@@ -118,38 +157,49 @@ __device__ void rhs(const ShellModel& m, const Region& q, double r, double v, do
     const double a = fmin(r, m.h_hi_cm) / q.h_g_i, b = fmin(r, q.h_old) / q.h_g_i;
     const double mass = q.m_g + q.m_co_hi * (a * a * a) + q.m_new + q.m_old * (b * b * b);
     dvdr = (-m.G * mass / (r * r) + momentum * l_bol / (m.c * q.m_g)) / v;
+    if constexpr (GAL) dvdr -= m.G * gs.gravity / v;
     dtdr = 1.0 / (v * m.year_s);
     if (r > m.r_escape) dvdr = -__builtin_inf();
 }
 
-__global__ void shell_rhs_kernel(const ShellModel m, const ShellRegions rg, int n, const int32_t* __restrict__ region,
-                                 const double* __restrict__ r, const double* __restrict__ v,
-                                 const double* __restrict__ t, double* __restrict__ dvdr, double* __restrict__ dtdr) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// GAL: one wave (= one workgroup of 64) per point, lane 0 stores; else one point per lane.
+template <bool GAL>
+__global__ void shell_rhs_kernel(const ShellModel m, const ShellRegions rg, const ShellGalaxy g, int n,
+                                 const int32_t* __restrict__ region, const double* __restrict__ r,
+                                 const double* __restrict__ v, const double* __restrict__ t, double* __restrict__ dvdr,
+                                 double* __restrict__ dtdr) {
+    const int i = GAL ? (int)blockIdx.x : (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (i >= n) return;
     const Region q = load_region(rg, region[i]);
+    const int view = GAL ? g.view_of_region[region[i]] : 0, self = GAL ? g.self_row[region[i]] : -1;
     double a, b;
-    rhs(m, q, r[i], v[i], t[i], a, b);
-    dvdr[i] = a;
-    dtdr[i] = b;
+    rhs<GAL>(m, g, view, self, q, r[i], v[i], t[i], a, b);
+    if (!GAL || threadIdx.x == 0) {
+        dvdr[i] = a;
+        dtdr[i] = b;
+    }
 }
 
-// Dormand-Prince 5(4), one region per thread.  Steps are capped by max_step and land exactly on the
-// n_out output radii r0 + (k+1)/n_out (r_end - r0).
-__global__ void shell_ode_kernel(const ShellModel m, const ShellRegions rg, const ShellControl ct,
+// Dormand-Prince 5(4), one region per thread (GAL: per wave, every lane with the same state, so control flow is
+// uniform and the shuffles of the row sums see all lanes; lane 0 stores).  Steps are capped by max_step and land
+// exactly on the n_out output radii r0 + (k+1)/n_out (r_end - r0).
+template <bool GAL>
+__global__ void shell_ode_kernel(const ShellModel m, const ShellRegions rg, const ShellGalaxy g, const ShellControl ct,
                                  ShellResult out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = GAL ? (int)blockIdx.x : (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (i >= rg.n) return;
+    const bool writer = !GAL || threadIdx.x == 0;
     const Region q = load_region(rg, i);
+    const int view = GAL ? g.view_of_region[i] : 0, self = GAL ? g.self_row[i] : -1;
     // beyond r_escape the reference sets dv/dr = -inf and its solver stops (MC code.py:951-953): integrate to there
     const double r0 = q.h_g_i, r_end = rg.r_end[i], r_stop = fmin(r_end, m.r_escape);
     double r = r0, v = ct.v0, t = ct.t0;
     double v_max = v, r_vmax = r, t_vmax = t;
     int status = RT_SHELL_REACHED_END, steps = 0, next_out = 0;
     double k1v, k1t;
-    rhs(m, q, r, v, t, k1v, k1t);
+    rhs<GAL>(m, g, view, self, q, r, v, t, k1v, k1t);
     double h = fmin(ct.max_step, 1e-3 * (r_end - r0));
-    for (int k = 0; k < ct.n_out; ++k) {
+    for (int k = 0; writer && k < ct.n_out; ++k) {
         out.v_out[(size_t)i * ct.n_out + k] = __builtin_nan("");
         out.t_out[(size_t)i * ct.n_out + k] = __builtin_nan("");
     }
@@ -174,16 +224,16 @@ __global__ void shell_ode_kernel(const ShellModel m, const ShellRegions rg, cons
         }
         // stages
         double k2v, k2t, k3v, k3t, k4v, k4t, k5v, k5t, k6v, k6t, k7v, k7t;
-        rhs(m, q, r + hs * (1.0 / 5.0), v + hs * (1.0 / 5.0) * k1v, t + hs * (1.0 / 5.0) * k1t, k2v, k2t);
-        rhs(m, q, r + hs * (3.0 / 10.0), v + hs * (3.0 / 40.0 * k1v + 9.0 / 40.0 * k2v),
+        rhs<GAL>(m, g, view, self, q, r + hs * (1.0 / 5.0), v + hs * (1.0 / 5.0) * k1v, t + hs * (1.0 / 5.0) * k1t, k2v, k2t);
+        rhs<GAL>(m, g, view, self, q, r + hs * (3.0 / 10.0), v + hs * (3.0 / 40.0 * k1v + 9.0 / 40.0 * k2v),
             t + hs * (3.0 / 40.0 * k1t + 9.0 / 40.0 * k2t), k3v, k3t);
-        rhs(m, q, r + hs * (4.0 / 5.0), v + hs * (44.0 / 45.0 * k1v - 56.0 / 15.0 * k2v + 32.0 / 9.0 * k3v),
+        rhs<GAL>(m, g, view, self, q, r + hs * (4.0 / 5.0), v + hs * (44.0 / 45.0 * k1v - 56.0 / 15.0 * k2v + 32.0 / 9.0 * k3v),
             t + hs * (44.0 / 45.0 * k1t - 56.0 / 15.0 * k2t + 32.0 / 9.0 * k3t), k4v, k4t);
-        rhs(m, q, r + hs * (8.0 / 9.0),
+        rhs<GAL>(m, g, view, self, q, r + hs * (8.0 / 9.0),
             v + hs * (19372.0 / 6561.0 * k1v - 25360.0 / 2187.0 * k2v + 64448.0 / 6561.0 * k3v - 212.0 / 729.0 * k4v),
             t + hs * (19372.0 / 6561.0 * k1t - 25360.0 / 2187.0 * k2t + 64448.0 / 6561.0 * k3t - 212.0 / 729.0 * k4t),
             k5v, k5t);
-        rhs(m, q, r + hs,
+        rhs<GAL>(m, g, view, self, q, r + hs,
             v + hs * (9017.0 / 3168.0 * k1v - 355.0 / 33.0 * k2v + 46732.0 / 5247.0 * k3v + 49.0 / 176.0 * k4v -
                       5103.0 / 18656.0 * k5v),
             t + hs * (9017.0 / 3168.0 * k1t - 355.0 / 33.0 * k2t + 46732.0 / 5247.0 * k3t + 49.0 / 176.0 * k4t -
@@ -196,7 +246,7 @@ __global__ void shell_ode_kernel(const ShellModel m, const ShellRegions rg, cons
         bool ok = isfinite(vn) && isfinite(tn) && vn > 0.0;
         double err = 2.0;
         if (ok) {
-            rhs(m, q, r + hs, vn, tn, k7v, k7t);
+            rhs<GAL>(m, g, view, self, q, r + hs, vn, tn, k7v, k7t);
             const double ev = hs * (71.0 / 57600.0 * k1v - 71.0 / 16695.0 * k3v + 71.0 / 1920.0 * k4v -
                                     17253.0 / 339200.0 * k5v + 22.0 / 525.0 * k6v - 1.0 / 40.0 * k7v);
             const double et = hs * (71.0 / 57600.0 * k1t - 71.0 / 16695.0 * k3t + 71.0 / 1920.0 * k4t -
@@ -219,8 +269,10 @@ __global__ void shell_ode_kernel(const ShellModel m, const ShellRegions rg, cons
                 t_vmax = t;
             }
             if (lands && to_sample && ct.n_out > 0 && next_out < ct.n_out) {
-                out.v_out[(size_t)i * ct.n_out + next_out] = v;
-                out.t_out[(size_t)i * ct.n_out + next_out] = t;
+                if (writer) {
+                    out.v_out[(size_t)i * ct.n_out + next_out] = v;
+                    out.t_out[(size_t)i * ct.n_out + next_out] = t;
+                }
                 ++next_out;
             }
             const double grow = err > 0.0 ? fmin(5.0, 0.9 * pow(err, -0.2)) : 5.0;
@@ -236,6 +288,7 @@ __global__ void shell_ode_kernel(const ShellModel m, const ShellRegions rg, cons
         }
     }
     if (status == RT_SHELL_REACHED_END && r_stop < r_end) status = RT_SHELL_ESCAPED;
+    if (!writer) return;
     out.v_max[i] = v_max;
     out.r_vmax[i] = r_vmax;
     out.t_vmax[i] = t_vmax;
@@ -248,19 +301,24 @@ __global__ void shell_ode_kernel(const ShellModel m, const ShellRegions rg, cons
 
 }  // namespace
 
-hipError_t launch_shell_rhs(const ShellModel& m, const ShellRegions& rg, int n, const int32_t* d_region,
-                            const double* d_r, const double* d_v, const double* d_t, double* d_dvdr, double* d_dtdr,
-                            hipStream_t stream) {
+hipError_t launch_shell_rhs(const ShellModel& m, const ShellRegions& rg, const ShellGalaxy* gal, int n,
+                            const int32_t* d_region, const double* d_r, const double* d_v, const double* d_t,
+                            double* d_dvdr, double* d_dtdr, hipStream_t stream) {
     if (n <= 0) return hipSuccess;
-    shell_rhs_kernel<<<(n + 63) / 64, 64, 0, stream>>>(m, rg, n, d_region, d_r, d_v, d_t, d_dvdr, d_dtdr);
+    if (gal)
+        shell_rhs_kernel<true><<<n, 64, 0, stream>>>(m, rg, *gal, n, d_region, d_r, d_v, d_t, d_dvdr, d_dtdr);
+    else
+        shell_rhs_kernel<false><<<(n + 63) / 64, 64, 0, stream>>>(m, rg, ShellGalaxy{}, n, d_region, d_r, d_v, d_t, d_dvdr, d_dtdr);
     return hipGetLastError();
 }
 
-hipError_t launch_shell_ode(const ShellModel& m, const ShellRegions& rg, const ShellControl& ct, const ShellResult& out,
-                            hipStream_t stream) {
+hipError_t launch_shell_ode(const ShellModel& m, const ShellRegions& rg, const ShellGalaxy* gal, const ShellControl& ct,
+                            const ShellResult& out, hipStream_t stream) {
     if (rg.n <= 0) return hipSuccess;
-    // 64 regions per workgroup: regions take very different numbers of steps, small groups keep CUs busy
-    shell_ode_kernel<<<(rg.n + 63) / 64, 64, 0, stream>>>(m, rg, ct, out);
+    if (gal)  // one wave per region
+        shell_ode_kernel<true><<<rg.n, 64, 0, stream>>>(m, rg, *gal, ct, out);
+    else  // 64 regions per workgroup: regions take very different numbers of steps, small groups keep CUs busy
+        shell_ode_kernel<false><<<(rg.n + 63) / 64, 64, 0, stream>>>(m, rg, ShellGalaxy{}, ct, out);
     return hipGetLastError();
 }
 

@@ -5,7 +5,7 @@ Mirrors, for all regions of a galaxy table at once,
     get_tau_IR          MC code.py:781-807
     GetRatios           MC code.py:1090-1157   (ratio_rp_lambda_rp, used by GetMC's tau_cutoff)
     GetMC               MC code.py:843-863
-    ODEs                MC code.py:905-955     (spherical shell, includeWholeGalaxy off)
+    ODEs                MC code.py:905-955     (spherical shell; includeWholeGalaxy through ShellGalaxy)
     GetRegionVelocity   MC code.py:1433-1472
 
 The integration itself runs in librt_amd.so (rt_shell_velocity); this module prepares its inputs from the
@@ -50,11 +50,54 @@ def ratio_rp_lambda_rp(l_edd, kappa_rp_ref, grain_type="mix", grain_mix=(0.5, 0.
     return k / float(kappa_rp_ref)
 
 
+class ShellGalaxy:
+    """gal_data as ODEs reads it with includeWholeGalaxy (MC code.py:919-920, 940-941): LHa_ratio_f and dist_to_ref
+    as [n_views, n_gal] (one view = the columns prepared for one region_ID), Mass_tot [n_gal], and per integrated
+    region its view and its own row of gal_data (-1: none, nothing is left out of the gravity sum)."""
+
+    def __init__(self, lha_ratio_f, dist_to_ref, mass_tot, view_of_region, self_row, ratio_rp_lambda_rp):
+        self.lha_ratio_f = np.ascontiguousarray(np.atleast_2d(lha_ratio_f), dtype=np.float64)
+        self.dist_to_ref = np.ascontiguousarray(np.atleast_2d(dist_to_ref), dtype=np.float64)
+        self.mass_tot = np.ascontiguousarray(mass_tot, dtype=np.float64)
+        self.view_of_region = np.ascontiguousarray(np.atleast_1d(view_of_region), dtype=np.int32)
+        self.self_row = np.ascontiguousarray(np.atleast_1d(self_row), dtype=np.int32)
+        self.ratio_rp_lambda_rp = float(ratio_rp_lambda_rp)
+        if self.lha_ratio_f.shape != self.dist_to_ref.shape or self.lha_ratio_f.shape[1] != len(self.mass_tot):
+            raise ValueError("lha_ratio_f and dist_to_ref must be [n_views, len(mass_tot)]")
+        if self.view_of_region.shape != self.self_row.shape:
+            raise ValueError("view_of_region and self_row must have one entry per integrated region")
+
+    @classmethod
+    def from_gal_data(cls, gal, rows, ratio_rp_lambda_rp, distance_pc):
+        """The set-up the reference keeps as comments (MC code.py:1682-1683), for every row in `rows` taken as
+        region_ID in turn: LHa_ratio_f = LHa exp(-tau ratio) / LHa[ref], dist_to_ref = Distance sqrt(tan^2(dRA) +
+        tan^2(dDec)) with RA, Dec in degrees.  `gal` maps the gal_data columns LHa, tau, RA, Dec, Mass_tot to
+        arrays; region k of the integration is gal_data row rows[k]."""
+        rows = np.atleast_1d(np.asarray(rows, dtype=np.int64))
+        lha, tau, ra, dec = (np.asarray(gal[k], float) for k in ("LHa", "tau", "RA", "Dec"))
+        lha_f = lha[None, :] * np.exp(-tau * ratio_rp_lambda_rp)[None, :] / lha[rows, None]
+        dist = distance_pc * np.sqrt(np.tan(np.radians(ra[None, :] - ra[rows, None])) ** 2
+                                     + np.tan(np.radians(dec[None, :] - dec[rows, None])) ** 2)
+        return cls(lha_f, dist, gal["Mass_tot"], np.arange(len(rows)), rows, ratio_rp_lambda_rp)
+
+    def c_struct(self, n_regions):
+        if len(self.view_of_region) != n_regions:
+            raise ValueError(f"the galaxy views are for {len(self.view_of_region)} regions, {n_regions} are integrated")
+        i32p = C.POINTER(C.c_int32)
+        g = abi.RtShellGalaxy(self.lha_ratio_f.shape[1], self.lha_ratio_f.shape[0], CM_PC, self.ratio_rp_lambda_rp,
+                              _dp(self.lha_ratio_f), _dp(self.dist_to_ref), _dp(self.mass_tot),
+                              self.view_of_region.ctypes.data_as(i32p), self.self_row.ctypes.data_as(i32p))
+        g._keep = self
+        return g
+
+
 class ShellModel:
-    """Everything ODEs reads that is not a property of one region."""
+    """Everything ODEs reads that is not a property of one region.  galaxy: a ShellGalaxy switches the reference's
+    includeWholeGalaxy terms on (MC code.py:118 has them off)."""
 
     def __init__(self, mc_tau, mc_ages, mc_values, *, time_slice=6.0, stellar_aging=False, static_momentum=False,
-                 tau_cutoff=0.0, l_ages=None, l_values=None, ratio_values=None, h_Hi=100.0):
+                 tau_cutoff=0.0, l_ages=None, l_values=None, ratio_values=None, h_Hi=100.0, galaxy=None):
+        self.galaxy = galaxy
         self.mc_tau = np.ascontiguousarray(mc_tau, dtype=np.float64)
         self.mc_ages = np.ascontiguousarray(mc_ages, dtype=np.float64)
         self.mc_values = np.ascontiguousarray(mc_values, dtype=np.float64)
@@ -90,15 +133,17 @@ class ShellModel:
         # BPASS_data[str(time_slice)].sum(): the tabulated value at time_slice (MC code.py:917)
         return float(self.l_values[hit[0]]) if len(hit) else float(np.interp(self.time_slice, self.l_ages, self.l_values))
 
-    def c_struct(self):
+    def c_struct(self, n_regions=0):
         n_l = 0 if self.l_ages is None else len(self.l_ages)
+        gal = None if self.galaxy is None else self.galaxy.c_struct(n_regions)
         m = abi.RtShellModel(int(self.stellar_aging), int(self.static_momentum), len(self.mc_tau), len(self.mc_ages), n_l, 0,
                              G_NEWTON, C_LIGHT, SIGMA_SB, YEAR_S, self.h_Hi * CM_PC, 10000 * CM_PC, self.time_slice,
                              self.tau_cutoff, self._l_norm(), _dp(self.mc_tau), _dp(self.mc_ages), _dp(self.mc_values),
                              None if self.l_ages is None else _dp(self.l_ages),
                              None if self.l_values is None else _dp(self.l_values),
-                             None if self.ratio_values is None else _dp(self.ratio_values))
-        m._keep = self
+                             None if self.ratio_values is None else _dp(self.ratio_values),
+                             None if gal is None else C.pointer(gal))
+        m._keep = (self, gal)
         return m
 
 
@@ -160,7 +205,7 @@ def shell_velocity(engine, model, regions, *, v_0=100.0, t_0=None, rtol=1e-8, at
     res = abi.RtShellResult(_dp(sol.v_max), _dp(sol.r_vmax), _dp(sol.t_vmax), _dp(sol.r_last), _dp(sol.v_last),
                             _dp(sol.t_last), sol.status.ctypes.data_as(C.POINTER(C.c_int32)),
                             sol.n_steps.ctypes.data_as(C.POINTER(C.c_int32)), _dp(sol.v_out), _dp(sol.t_out))
-    m, r = model.c_struct(), regions.c_struct()
+    m, r = model.c_struct(regions.n), regions.c_struct()
     engine._check(engine._lib.rt_shell_velocity(engine._ctx, C.byref(m), C.byref(r), C.byref(ctl), C.byref(res)))
     if n_out:
         frac = (np.arange(n_out) + 1.0) / n_out
@@ -173,7 +218,7 @@ def shell_rhs(engine, model, regions, region_index, r, v, t):
     idx = np.ascontiguousarray(region_index, dtype=np.int32)
     r, v, t = (np.ascontiguousarray(np.broadcast_to(np.asarray(x, float), idx.shape), dtype=np.float64) for x in (r, v, t))
     dvdr, dtdr = np.empty(len(idx)), np.empty(len(idx))
-    m, rg = model.c_struct(), regions.c_struct()
+    m, rg = model.c_struct(regions.n), regions.c_struct()
     engine._check(engine._lib.rt_shell_rhs(engine._ctx, C.byref(m), C.byref(rg), len(idx),
                                            idx.ctypes.data_as(C.POINTER(C.c_int32)), _dp(r), _dp(v), _dp(t), _dp(dvdr),
                                            _dp(dtdr)))

@@ -39,6 +39,7 @@ def test_header_is_plain_c_and_layouts_match_ctypes(rt, tmp_path):
     A = rt._abi
     pairs = {"rt_params": A.RtParams, "rt_tallies": A.RtTallies, "rt_photon_trace": A.RtPhotonTrace,
              "rt_grain_set": A.RtGrainSet, "rt_grain_tables": A.RtGrainTables, "rt_shell_model": A.RtShellModel,
+             "rt_shell_galaxy": A.RtShellGalaxy,
              "rt_shell_regions": A.RtShellRegions, "rt_shell_control": A.RtShellControl, "rt_shell_result": A.RtShellResult}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "rt_amd.h"', 'int main(void) {']
     for cname, ct in pairs.items():

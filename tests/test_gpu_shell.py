@@ -120,3 +120,91 @@ def test_errors(rt, engine):
         shell.shell_velocity(engine, bad, make_regions())
     with pytest.raises(rt.RtError):
         shell.shell_velocity(engine, make_model(), make_regions(r_end=1.0))
+
+
+# ---- with the galaxy's other regions (the reference's includeWholeGalaxy flag, MC code.py:919-920, 940-941) ----
+ZG = np.load(os.path.join(os.path.dirname(__file__), "golden", "shell_galaxy.npz"))
+
+
+def galaxy_setup(rows, aging=False, r_end=None):
+    gal = {k[4:]: ZG[k] for k in ZG.files if k.startswith("gal_")}
+    rows = np.asarray(rows)
+    sub = {k: np.asarray(v)[rows] for k, v in gal.items()}
+    regions = shell.ShellRegions.from_gal_data(sub, h_g=float(Z["h_g"]), r_end=r_end)
+    g = shell.ShellGalaxy.from_gal_data(gal, rows, float(ZG["ratio_rp_lambda_rp"]), float(ZG["distance_pc"]))
+    m = make_model(aging)
+    m.galaxy = g
+    return m, regions
+
+
+@pytest.mark.parametrize("case", ["plain", "aging"])
+def test_whole_galaxy_rhs_matches_reference(engine, case):
+    m, regions = galaxy_setup(ZG["view_rows"], aging=case == "aging")
+    dvdr, dtdr = shell.shell_rhs(engine, m, regions, ZG["rhs_view"], ZG["rhs_r"], ZG["rhs_v"], ZG["rhs_t"])
+    want = ZG["rhs_" + case]
+    fin, esc = np.isfinite(want[:, 0]), np.isneginf(want[:, 0])
+    assert np.all(np.isneginf(dvdr[esc])) and esc.sum() >= 1
+    assert np.all(np.abs(dvdr[fin] - want[fin, 0]) <= 1e-11 * np.abs(want[fin, 0]) + 1e-24), \
+        np.max(np.abs(dvdr[fin] / want[fin, 0] - 1))
+    assert np.all(np.abs(dtdr[fin] - want[fin, 1]) <= 1e-14 * np.abs(want[fin, 1]))
+    assert fin.sum() > 0.6 * len(want)
+    # and the stored views themselves, handed over as they are
+    m.galaxy = shell.ShellGalaxy(ZG["view_LHa_ratio_f"], ZG["view_dist_to_ref"], ZG["gal_Mass_tot"], np.arange(3), ZG["view_rows"],
+                                 float(ZG["ratio_rp_lambda_rp"]))
+    dvdr2, _ = shell.shell_rhs(engine, m, regions, ZG["rhs_view"], ZG["rhs_r"], ZG["rhs_v"], ZG["rhs_t"])
+    assert np.all(np.abs(dvdr2[fin] - want[fin, 0]) <= 1e-11 * np.abs(want[fin, 0]) + 1e-24)
+
+
+def test_whole_galaxy_trajectories(engine):
+    """The stored trajectory of the reference's right-hand side (region row 0), and every one of the 48 regions of
+    the stored gal_data, each seen from its own place, against scipy on the pinned restatement."""
+    n_out = len(ZG["traj_v"])
+    span = float(ZG["traj_span_pc"]) * CM_PC
+    rows = np.arange(int(ZG["n_gal"]))
+    m, regions = galaxy_setup(rows, r_end=float(Z["h_g"]) * CM_PC + span)
+    sol = shell.shell_velocity(engine, m, regions, v_0=float(Z["v_0"]), t_0=float(Z["t_0"]), n_out=n_out, rtol=1e-11)
+    i = int(ZG["view_rows"][0])
+    ok = np.isfinite(ZG["traj_v"]) & np.isfinite(sol.v_out[i])
+    assert ok.sum() >= n_out // 2
+    np.testing.assert_allclose(sol.v_out[i][ok], ZG["traj_v"][ok], rtol=2e-6, atol=5e-6 * np.nanmax(ZG["traj_v"]))
+    np.testing.assert_allclose(sol.t_out[i][ok], ZG["traj_t"][ok], rtol=5e-6)
+    mo = shell_ode.Model(Z)
+    compared = 0
+    for i in rows[::4]:
+        q = shell_ode.Region.__new__(shell_ode.Region)
+        q.M_g, q.M_new, q.M_old, q.M_CO_Hi = (float(ZG["gal_Mass_g"][i]), float(ZG["gal_Mass_new"][i]),
+                                              float(ZG["gal_Mass_old"][i]), 0.0)
+        q.H_old, q.tau_i, q.L_Bol, q.Sigma_g = (float(ZG["gal_H_old"][i]), float(ZG["gal_tau"][i]), float(ZG["gal_L_Bol"][i]),
+                                                float(ZG["gal_Sigma_g"][i]))
+        q.h_g_i = float(Z["h_g"]) * CM_PC
+        view = shell_ode.Galaxy(m.galaxy.lha_ratio_f[i], m.galaxy.dist_to_ref[i], ZG["gal_Mass_tot"], int(i),
+                                float(ZG["ratio_rp_lambda_rp"]))
+        v, t, r_stop, status, _ = shell_ode.integrate_region(mo, q, q.h_g_i + span, float(Z["v_0"]), float(Z["t_0"]), n_out,
+                                                             rtol=1e-12, gal=view)
+        ok = np.isfinite(v) & np.isfinite(sol.v_out[i])
+        np.testing.assert_allclose(sol.v_out[i][ok], v[ok], rtol=5e-6, atol=5e-6 * (np.nanmax(v) if ok.any() else 0.0))
+        np.testing.assert_allclose(sol.t_out[i][ok], t[ok], rtol=5e-6)
+        compared += int(ok.sum())
+        if status != 0:
+            assert sol.status[i] == shell.abi.SHELL_STALLED and abs(sol.r_last[i] - r_stop) <= 2e-3 * r_stop
+        else:
+            assert sol.status[i] == shell.abi.SHELL_REACHED_END
+    assert compared >= 30
+    # without the other regions the same shells move differently: the terms are not a no-op here
+    m.galaxy = None
+    alone = shell.shell_velocity(engine, m, regions, v_0=float(Z["v_0"]), t_0=float(Z["t_0"]), n_out=n_out, rtol=1e-11)
+    assert np.nanmax(np.abs(alone.v_max / sol.v_max - 1)) > 0.05
+
+
+def test_whole_galaxy_errors(rt, engine):
+    m, regions = galaxy_setup(ZG["view_rows"])
+    m.galaxy.view_of_region[1] = 7
+    with pytest.raises(rt.RtError, match="names view 7 of 3"):
+        shell.shell_rhs(engine, m, regions, [0], 1e20, 1e3, 1e7)
+    m, regions = galaxy_setup(ZG["view_rows"])
+    m.galaxy.self_row[0] = 48
+    with pytest.raises(rt.RtError, match="names row 48 of 48"):
+        shell.shell_rhs(engine, m, regions, [0], 1e20, 1e3, 1e7)
+    m, _ = galaxy_setup(ZG["view_rows"])
+    with pytest.raises(ValueError, match="3 regions"):
+        shell.shell_velocity(engine, m, make_regions())

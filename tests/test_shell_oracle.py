@@ -76,3 +76,63 @@ def test_host_ratio_and_cutoff():
     tau = np.array([1e-5, 0.01, 0.3, 4.0])
     for age in (6.0, 7.25):
         np.testing.assert_allclose(shell.get_mc(m, tau, age), [shell_ode.get_mc(ref, float(x), age) for x in tau], rtol=1e-13)
+
+
+# ---- with the galaxy's other regions (the reference's includeWholeGalaxy flag) ----
+ZG = np.load(os.path.join(os.path.dirname(__file__), "golden", "shell_galaxy.npz"))
+
+
+def galaxy_region(row):
+    """Row `row` of the stored gal_data as the regionData of ODEs."""
+    q = shell_ode.Region.__new__(shell_ode.Region)
+    q.M_g, q.M_new, q.M_old, q.M_CO_Hi = (float(ZG["gal_Mass_g"][row]), float(ZG["gal_Mass_new"][row]),
+                                          float(ZG["gal_Mass_old"][row]), 0.0)
+    q.H_old, q.tau_i, q.L_Bol, q.Sigma_g = (float(ZG["gal_H_old"][row]), float(ZG["gal_tau"][row]),
+                                            float(ZG["gal_L_Bol"][row]), float(ZG["gal_Sigma_g"][row]))
+    q.h_g_i = float(Z["h_g"]) * shell_ode.CM_PC
+    return q
+
+
+def galaxy_view(k):
+    return shell_ode.Galaxy(ZG["view_LHa_ratio_f"][k], ZG["view_dist_to_ref"][k], ZG["gal_Mass_tot"], int(ZG["view_rows"][k]),
+                            float(ZG["ratio_rp_lambda_rp"]))
+
+
+@pytest.mark.parametrize("case", ["plain", "aging"])
+def test_whole_galaxy_rhs_matches_reference(case):
+    m = shell_ode.Model(Z, aging=case == "aging")
+    want = ZG["rhs_" + case]
+    got = np.array([shell_ode.rhs(ZG["rhs_r"][j], (ZG["rhs_v"][j], ZG["rhs_t"][j]), m,
+                                  galaxy_region(int(ZG["view_rows"][ZG["rhs_view"][j]])), galaxy_view(int(ZG["rhs_view"][j])))
+                    for j in range(len(want))])
+    n = same(got[:, 0], want[:, 0], 1e-12)
+    same(got[:, 1], want[:, 1], 1e-14)
+    assert n > 0.6 * len(want)
+    # the flag matters at these points: the other regions' light and gravity change dv/dr by up to a factor
+    fin = np.isfinite(ZG["rhs_plain"][:, 0])
+    assert np.max(np.abs(ZG["rhs_plain"][fin, 0] / ZG["rhs_plain_flag_off"][fin, 0] - 1)) > 0.5
+
+
+def test_whole_galaxy_trajectory_matches_reference():
+    m, row = shell_ode.Model(Z), int(ZG["view_rows"][0])
+    q = galaxy_region(row)
+    n_out = len(ZG["traj_v"])
+    v, t, r_stop, _, _ = shell_ode.integrate_region(m, q, q.h_g_i + float(ZG["traj_span_pc"]) * shell_ode.CM_PC, float(Z["v_0"]),
+                                                    float(Z["t_0"]), n_out, rtol=1e-12, gal=galaxy_view(0))
+    ok = np.isfinite(ZG["traj_v"]) & np.isfinite(v)
+    assert ok.sum() >= n_out // 2
+    np.testing.assert_allclose(v[ok], ZG["traj_v"][ok], rtol=1e-6, atol=5e-6 * np.nanmax(ZG["traj_v"]))
+    np.testing.assert_allclose(t[ok], ZG["traj_t"][ok], rtol=5e-6)
+    assert abs(r_stop - float(ZG["traj_rstop"])) <= 1e-3 * float(ZG["traj_rstop"])
+
+
+def test_host_galaxy_views():
+    """ShellGalaxy.from_gal_data follows the set-up the reference keeps in comments (MC code.py:1682-1683); the
+    stored views were formed with pandas by the same recipe."""
+    gal = {k: ZG["gal_" + k] for k in ("LHa", "tau", "RA", "Dec", "Mass_tot")}
+    g = shell.ShellGalaxy.from_gal_data(gal, ZG["view_rows"], float(ZG["ratio_rp_lambda_rp"]), float(ZG["distance_pc"]))
+    np.testing.assert_allclose(g.lha_ratio_f, ZG["view_LHa_ratio_f"], rtol=1e-14)
+    np.testing.assert_allclose(g.dist_to_ref, ZG["view_dist_to_ref"], rtol=1e-12, atol=0)
+    assert np.array_equal(g.self_row, ZG["view_rows"]) and np.array_equal(g.view_of_region, np.arange(len(ZG["view_rows"])))
+    for k, row in enumerate(ZG["view_rows"]):
+        assert g.dist_to_ref[k, row] == 0.0 and g.lha_ratio_f[k, row] == pytest.approx(np.exp(-gal["tau"][row] * g.ratio_rp_lambda_rp))
