@@ -130,13 +130,25 @@ def RunPhotonsGray(tau_atm, num_photons, boundary, albedo, scatter, g, *, rand_m
 # ----------------------------------------------------------------------------------------------
 # runMC
 # ----------------------------------------------------------------------------------------------
+BPASS_LOG_AGES = tuple(f"{6.0 + 0.1 * i:.1f}" for i in range(51))  # the 51 ages of every BPASS v2 output table
+
+
 def read_bpass_spectra(path):
-    """A BPASS 'spectra-*.dat' file as {column name: array}: 'WL' (Angstrom) and the 51 log-age
-    columns '6.0' ... '11.0', the layout hoki.load.model_output gives the reference (MC code.py:1013)."""
-    data = np.loadtxt(path)
-    cols = {"WL": data[:, 0]}
-    for i in range(1, data.shape[1]):
-        cols[f"{6.0 + 0.1 * (i - 1):.1f}"] = data[:, i]
+    """A BPASS 'spectra-*.dat' file as {column name: array}: 'WL' (Angstrom) and the 51 log-age columns '6.0' ...
+    '11.0' that the reference indexes as BPASS_data[str(time_slice)] (MC code.py:1013, :917).  The file is a
+    whitespace-separated table of Fortran E-format numbers, one row per wavelength, like the BPASS tables of the
+    same model that ship with the reference (ionizing-*.dat, colours-*.dat: one row per age, the same 51 ages).
+    Anything else -- another column count, a wavelength column that does not ascend, a non-number -- raises
+    ValueError instead of being read as something it is not."""
+    data = np.loadtxt(path, ndmin=2)
+    if data.shape[1] != 1 + len(BPASS_LOG_AGES):
+        raise ValueError(f"{path}: {data.shape[1]} columns; a BPASS spectra file has 52 (wavelength + 51 ages)")
+    wl = data[:, 0]
+    if not (np.all(np.isfinite(data)) and np.all(wl > 0) and np.all(np.diff(wl) > 0)):
+        raise ValueError(f"{path}: the wavelength column must be positive and ascending, and every entry finite")
+    cols = {"WL": wl}
+    for i, name in enumerate(BPASS_LOG_AGES):
+        cols[name] = data[:, i + 1]
     return cols
 
 
