@@ -920,7 +920,7 @@ int check_shell_galaxy(const rt_shell_galaxy* g, int n_regions) {
     }
     const size_t cells = (size_t)g->n_gal * (size_t)g->n_views;
     for (size_t k = 0; k < cells; ++k)
-        if (g->dist_to_ref[k] < 0.0) return fail(RT_ERR_INVALID, "galaxy: dist_to_ref[%zu] is negative", k);
+        if (!(g->dist_to_ref[k] >= 0.0)) return fail(RT_ERR_INVALID, "galaxy: dist_to_ref[%zu] is negative or not a number", k);
     return RT_OK;
 }
 
