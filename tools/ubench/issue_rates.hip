@@ -209,6 +209,35 @@ KERNEL32_EXEC(k_xor_exec4, 0xFull, "v_xor_b32 %0, %0, %4\n v_xor_b32 %1, %1, %4\
 KERNEL32_EXEC(k_fma32_exec4, 0xFull, "v_fma_f32 %0, %0, %4, %4\n v_fma_f32 %1, %1, %4, %4\n v_fma_f32 %2, %2, %4, %4\n v_fma_f32 %3, %3, %4, %4\n")
 KERNEL32_EXEC(k_fma32_exec64, 0xFFFFFFFFFFFFFFFFull, "v_fma_f32 %0, %0, %4, %4\n v_fma_f32 %1, %1, %4, %4\n v_fma_f32 %2, %2, %4, %4\n v_fma_f32 %3, %3, %4, %4\n")
 
+// Conversions between fp64 and 32-bit integers / fp32 (no dependency chain: the issue rate is what is measured).
+#define KERNEL_CVT(name, INSTR, TO, TI, INIT)                                                         \
+    __global__ __launch_bounds__(256) void name(uint32_t* out, unsigned long long* clk) {             \
+        TO x = 0, y = 0, z = 0, w = 0;                                                                \
+        TI a = (TI)(INIT + threadIdx.x), b = (TI)(INIT + 1), c = (TI)(INIT + 2), d = (TI)(INIT + 3);  \
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();                                   \
+        const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();                               \
+        for (int it = 0; it < kIters; ++it) {                                                         \
+            asm volatile(REP16(INSTR " %0, %4\n " INSTR " %1, %5\n " INSTR " %2, %6\n " INSTR " %3, %7\n")              \
+                         : "+v"(x), "+v"(y), "+v"(z), "+v"(w) : "v"(a), "v"(b), "v"(c), "v"(d));      \
+        }                                                                                             \
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime();                                   \
+        const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();                               \
+        out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)x ^ (uint32_t)y ^ (uint32_t)z ^ (uint32_t)w; \
+        if (threadIdx.x == 0 && blockIdx.x == 0) { clk[0] = t1 - t0; clk[1] = r1 - r0; }              \
+    }
+KERNEL_CVT(k_cvt_i32_f64, "v_cvt_i32_f64", uint32_t, double, 1.5)
+KERNEL_CVT(k_cvt_u32_f64, "v_cvt_u32_f64", uint32_t, double, 1.5)
+KERNEL_CVT(k_cvt_f64_i32, "v_cvt_f64_i32", double, uint32_t, 3)
+KERNEL_CVT(k_cvt_f64_u32, "v_cvt_f64_u32", double, uint32_t, 3)
+KERNEL_CVT(k_cvt_f32_f64, "v_cvt_f32_f64", float, double, 1.5)
+KERNEL_CVT(k_cvt_f64_f32, "v_cvt_f64_f32", double, float, 1.5)
+KERNEL_CVT(k_floor_f64, "v_floor_f64", double, double, 1.5)
+KERNEL_CVT(k_fract_f64, "v_fract_f64", double, double, 1.5)
+KERNEL_CVT(k_frexp_mant_f64, "v_frexp_mant_f64", double, double, 1.5)
+KERNEL_CVT(k_frexp_exp_f64, "v_frexp_exp_i32_f64", uint32_t, double, 1.5)
+KERNEL_CVT(k_sqrt_f64, "v_sqrt_f64", double, double, 1.5)
+KERNEL_CVT(k_rcp_f32, "v_rcp_f32", float, float, 1.5)
+
 int main() {
     uint32_t* d_out;
     unsigned long long* d_clk;
@@ -226,5 +255,7 @@ int main() {
     run("k_fma64 (1 wave)", k_fma64, 1, d_out, d_clk);
     run("k_fma64 (2 waves)", k_fma64, 2, d_out, d_clk);
     RUN(k_fma64_exec32); RUN(k_fma64_exec16); RUN(k_fma64_exec1); RUN(k_fma64_exec_hi32); RUN(k_fma64_exec_even); RUN(k_fma64_exec2); RUN(k_fma64_exec4); RUN(k_fma64_exec8); RUN(k_fma64_exec1_lane37); RUN(k_fma64_exec2_far); RUN(k_fma64_exec12); RUN(k_fma64_exec9); RUN(k_fma64_exec15); RUN(k_fma64_exec8_spread); RUN(k_fma64_exec16_spread); RUN(k_mullo_exec4); RUN(k_xor_exec4); RUN(k_fma32_exec4); RUN(k_fma32_exec64);
+    RUN(k_cvt_i32_f64); RUN(k_cvt_u32_f64); RUN(k_cvt_f64_i32); RUN(k_cvt_f64_u32); RUN(k_cvt_f32_f64); RUN(k_cvt_f64_f32);
+    RUN(k_floor_f64); RUN(k_fract_f64); RUN(k_frexp_mant_f64); RUN(k_frexp_exp_f64); RUN(k_sqrt_f64); RUN(k_rcp_f32);
     return 0;
 }
