@@ -421,7 +421,9 @@ int enqueue_sweep(rt_ctx* ctx, const rt_params* p, void* d_slab_sums, void* d_co
 
     {   // the cheapest items (end of the list) stay in order for the end of the launch: two per resident wave
         // (measured: 0 costs 2 %, 1 to 8 per wave are equal)
-        const unsigned long long tail = std::min<unsigned long long>(items / 8, (unsigned long long)grid * 4 * 2);
+        unsigned tail_per_wave = 2u, tail_cap_div = 8u;
+        rt::Ablation::tail_rule(tail_per_wave, tail_cap_div);  // product builds: no-op
+        const unsigned long long tail = std::min<unsigned long long>(items / tail_cap_div, (unsigned long long)grid * 4 * tail_per_wave);
         const unsigned long long rows = rt::kQueueRows;
         // worth it from about 8 items per resident wave on; a shorter launch is decided by the balance of its end,
         // which the plain heaviest-first order serves best (measured: -4 % at 5 items per wave, +1.5 % at 10, +3.5 % at 24)

@@ -22,6 +22,7 @@ struct Ablation {  // the product's values of the switches the timing experiment
     static bool chunk_rule(unsigned&, unsigned&) { return false; }
     static int scatter_quorum(int product) { return product; }
     static int interleave_min(int product) { return product; }
+    static void tail_rule(unsigned&, unsigned&) {}
 };
 }  // namespace rt
 #endif

@@ -10,6 +10,8 @@
 //   -DRT_ABL_DIV_GENERAL       the general fp64 division instead of the unscaled sequence
 //   -DRT_ABL_WAVE_TRACE        per-wave start / last-chunk / end clocks of the last walk launch (tools/wave_trace.py)
 //   RT_AMD_CHUNK=thin,thick    (environment, read at load) chunk lengths for atmospheres below / above tau = 0.5
+//   RT_AMD_ILV=n               (environment) chunks per resident wave from which the queue is walked in interleaved rows
+//   RT_AMD_TAIL=per_wave,div   (environment) length of the ordered tail of the queue
 //   RT_AMD_QUORUM=n            (environment) scattering lanes a wave gathers before it scatters (0 = never wait)
 #pragma once
 #include <cstdio>
@@ -63,6 +65,16 @@ struct Ablation {
         const char* e = getenv("RT_AMD_ILV");
         const int v = e ? atoi(e) : -1;
         return v >= 0 ? v : product;
+    }
+    // RT_AMD_TAIL=per_wave,cap_div (environment): the cheapest per_wave chunks per resident wave stay in order at the end
+    // of the queue, at most items / cap_div of them
+    static void tail_rule(unsigned& per_wave, unsigned& cap_div) {
+        const char* e = getenv("RT_AMD_TAIL");
+        unsigned a = 0, b = 0;
+        if (e && sscanf(e, "%u,%u", &a, &b) == 2 && b >= 1) {
+            per_wave = a;
+            cap_div = b;
+        }
     }
     // RT_AMD_QUORUM=n (environment): how many scattering lanes a wave gathers before it runs the scattering code
     static int scatter_quorum(int product) {
