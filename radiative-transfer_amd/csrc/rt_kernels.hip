@@ -126,7 +126,18 @@ __device__ __forceinline__ bool pop_item(const Sweep& sw, unsigned int* d_next, 
     if (lane == 0) q = atomicAdd(d_next, 1u);
     q = __builtin_amdgcn_readfirstlane(q);
     if (q >= sw.n_items) return false;
-    if (q < sw.n_interleaved) q = (q & (kQueueRows - 1u)) * sw.row_len + (q >> kQueueRowsLog2);
+    if (sw.mix_groups) {
+        const uint32_t per = sw.mix_rh + sw.mix_rl, mixed = sw.mix_groups * per;
+        if (q < mixed) {
+            const uint32_t g = q / per, p = q - g * per;
+            q = p < sw.mix_rh ? g * sw.mix_rh + p : sw.mix_h + g * sw.mix_rl + (p - sw.mix_rh);
+        } else {
+            const uint32_t t = q - mixed, rem_h = sw.mix_h - sw.mix_groups * sw.mix_rh;
+            q = t < rem_h ? sw.mix_groups * sw.mix_rh + t : sw.mix_h + sw.mix_groups * sw.mix_rl + (t - rem_h);
+        }
+    } else if (q < sw.n_interleaved) {
+        q = (q & (kQueueRows - 1u)) * sw.row_len + (q >> kQueueRowsLog2);
+    }
     // Sorted position lo with item_prefix[lo] <= q < item_prefix[lo+1], searched 64 ways at a time: every lane
     // reads one entry of the candidate range, a ballot picks the sub-range -- two dependent loads for up to 4096
     // atmospheres where a binary search has twelve (the wave idles through each of them once per chunk).

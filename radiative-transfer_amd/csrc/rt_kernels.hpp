@@ -39,6 +39,9 @@ struct Sweep {
     // from the first wave to (almost) the last; the remaining items, the cheapest of the list, follow in order
     // and keep the end of the launch balanced.
     uint32_t n_interleaved, row_len;
+    // Or (mix_groups > 0): the first mix_h items of the list, the heavy ones, alternate with the light ones behind them,
+    // mix_rh heavy then mix_rl light per group for mix_groups groups; what is left follows in list order.
+    uint32_t mix_h, mix_rh, mix_rl, mix_groups;
 };
 
 constexpr uint32_t kQueueRowsLog2 = 3;  // measured: 2 to 1024 rows give the same time, 8192 rows 1 % more

@@ -23,6 +23,7 @@ struct Ablation {  // the product's values of the switches the timing experiment
     static int scatter_quorum(int product) { return product; }
     static int interleave_min(int product) { return product; }
     static void tail_rule(unsigned&, unsigned&) {}
+    static bool mix_rule(double&, double&) { return false; }
 };
 }  // namespace rt
 #endif

@@ -127,7 +127,7 @@ def test_slabs_beyond_the_last_photon(rt, engine, c_oracle):
 
 def test_results_do_not_depend_on_the_work_order(rt, engine):
     """A launch with many chunks per resident wave (here 52 000 over 5120 waves) hands them out in interleaved
-    rows, a short one heaviest first.  A chunk's tallies depend on its photon ids only, so the first 100 of 500
+    rows, a short one alternates the chunks of thick and thin atmospheres.  A chunk's tallies depend on its photon ids only, so the first 100 of 500
     atmospheres in one launch give, bit for bit, what a launch of those 100 alone gives (same atmosphere
     indices, hence the same Philox counters)."""
     t = table()
@@ -140,6 +140,15 @@ def test_results_do_not_depend_on_the_work_order(rt, engine):
     assert np.array_equal(first.counts, whole.counts[:100])
     assert np.array_equal(first.mu_hist, whole.mu_hist[:100])
     assert np.array_equal(first.sums, whole.sums[:100])
+    # a short launch with thick and thin atmospheres (5200 chunks over 5120 waves) alternates thick and thin chunks;
+    # every other atmosphere of it alone, at its own index, is a different list in a different order
+    tau = np.logspace(-3, 2, 50)
+    short = engine.run(rt.make_params(tau, n, n_mu_bins=10))
+    half = engine.run(rt.make_params(tau, np.where(np.arange(50) % 2 == 0, n, 0), n_mu_bins=10))
+    pick = np.arange(50) % 2 == 0
+    assert np.array_equal(half.counts[pick], short.counts[pick]) and np.all(half.counts[~pick] == 0)
+    assert np.array_equal(half.mu_hist[pick], short.mu_hist[pick])
+    assert np.array_equal(half.sums[pick], short.sums[pick])
 
 
 def test_histogram_limit_is_reported_before_any_device_work(rt, engine):

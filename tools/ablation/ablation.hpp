@@ -12,6 +12,7 @@
 //   RT_AMD_CHUNK=thin,thick    (environment, read at load) chunk lengths for atmospheres below / above tau = 0.5
 //   RT_AMD_ILV=n               (environment) chunks per resident wave from which the queue is walked in interleaved rows
 //   RT_AMD_TAIL=per_wave,div   (environment) length of the ordered tail of the queue
+//   RT_AMD_MIX=tau,beta        (environment) heavy / light alternation of the queue instead of the rows
 //   RT_AMD_QUORUM=n            (environment) scattering lanes a wave gathers before it scatters (0 = never wait)
 #pragma once
 #include <cstdio>
@@ -75,6 +76,16 @@ struct Ablation {
             per_wave = a;
             cap_div = b;
         }
+    }
+    // RT_AMD_MIX=tau_split,beta (environment): chunks of atmospheres with tau >= tau_split alternate with the share beta
+    // of the chunks of the thinner ones; the rest of the thin chunks follows in order
+    static bool mix_rule(double& tau_split, double& beta) {
+        const char* e = getenv("RT_AMD_MIX");
+        double a = 0, b = 0;
+        if (!e || sscanf(e, "%lf,%lf", &a, &b) != 2 || !(b > 0.0 && b <= 1.0)) return false;
+        tau_split = a;
+        beta = b;
+        return true;
     }
     // RT_AMD_QUORUM=n (environment): how many scattering lanes a wave gathers before it runs the scattering code
     static int scatter_quorum(int product) {
