@@ -200,3 +200,34 @@ def test_which_kernel_serves_which_flags(rt, engine):
     for kw, name in want:
         engine.run(rt.make_params(tau, 2000, **kw))
         assert name in engine.last_kernel(), (kw, engine.last_kernel())
+
+
+@pytest.mark.parametrize("order,boundary,scatter", [("mc", "reflect", "hg"), ("mc", "absorb", "hg"), ("mc", "reflect", "iso"),
+                                                    ("gray", "reflect", "hg"), ("gray", "absorb", "iso")])
+def test_production_sweep_equals_the_reference_restatement_on_its_own_streams(rt, engine, order, boundary, scatter):
+    """The production (Philox) sweep against oracle/numpy_walk.py -- the vectorised restatement that reproduces the
+    reference's seeded runs bit for bit -- fed, photon by photon, the uniforms the device draws (oracle/philox.py):
+    the same histories, so the same counts and, to 1e-12, the same three momenta of runMC's estimator.  One
+    wavelength (monochromatic), so that the emission draw plays no part."""
+    from oracle import numpy_walk as nw
+    from oracle import philox
+    A = rt._abi
+    wl0, g0, alb0, sc0 = 0.55, 0.63, 0.82, 1.3
+    engine.set_tables([wl0], [g0], [alb0], [sc0])
+    h = 1.0 if order == "gray" else rt.H_PLANCK
+    tau, n, seed, base = np.array([0.3, 3.0]), 20000, 0x1234ABCD5678, 777
+    res = engine.run(rt.make_params(tau, n, order=order, boundary=boundary, scatter=scatter, monochromatic=wl0, h=h, seed=seed,
+                                    photon_id_base=base, n_mu_bins=10))
+    for a in range(len(tau)):
+        stream = nw.PerPhotonStream(n, lambda ids, j, a=a: philox.walk_uniform(np.asarray(ids, dtype=np.uint64) + np.uint64(base), j, a, seed))
+        ref = nw.run_photons(tau[a], np.full(n, wl0), np.full(n, g0), np.full(n, alb0), np.full(n, sc0), np.ones(n),
+                             boundary=boundary, scatter=scatter, order=order, stream=stream, h=h)
+        c = res.counts[a].astype(np.int64)
+        assert c[A.CNT_SCATTER] == ref["scatter_count"] and c[A.CNT_ESCAPED] == ref["n_escaped"]
+        assert c[A.CNT_ESCAPED_UNCOUNTED] == ref["n_escaped_uncounted"] and c[A.CNT_ABSORBED] == ref["n_absorbed"]
+        assert c[A.CNT_BOUNDARY_ABSORBED] == ref["n_boundary_absorbed"] and c[A.CNT_GUARD] == 0
+        for k, name in ((A.SUM_INITIAL, "initial_momentum"), (A.SUM_ESCAPED, "escaped_momentum"), (A.SUM_BOUNDARY, "boundary_momentum")):
+            assert abs(res.sums[a, k] - ref[name]) <= 1e-12 * abs(ref[name]) + 1e-14 * abs(ref["initial_momentum"]), (name, res.sums[a, k], ref[name])
+        emu = np.sort(ref["escaped_mu"])
+        bins = np.minimum(np.floor(10 * emu).astype(int), 10)
+        assert np.array_equal(np.bincount(bins, minlength=11), res.mu_hist[a].astype(np.int64))
