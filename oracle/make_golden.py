@@ -131,9 +131,12 @@ def replay_reference(order, case):
 
 
 def make_case(name, order, n, tau, boundary, scatter, seed, abs_only=0, rand_mu0=False, gray_albedo=0.9, gray_g=0.5,
-              tiny_g=False):
+              tiny_g=False, uniform=None):
     rng = np.random.default_rng(seed)
-    if order == "mc":
+    if uniform is not None:  # (lambda, g, albedo, scale) the same for every photon: what a one-wavelength table gives, so
+        # that a PRODUCTION sweep under the same seed walks the very same histories (tests/test_gpu_replay.py)
+        lam, g, alb, scale = (np.full(n, float(v)) for v in uniform)
+    elif order == "mc":
         lam = np.round(rng.uniform(0.1, 2.0, n), 4)
         g = rng.uniform(0.05, 0.95, n) * np.where(rng.random(n) < 0.15, -1.0, 1.0)
         if tiny_g:  # number-weighted MRN averages give g as small as 1e-7 (cancellation in the HG formula)
@@ -163,6 +166,15 @@ REPLAY_CASES = [
     make_case("gray_reemit_iso_tau10", "gray", 600, 10.0, "reemit", "iso", 202, gray_albedo=1.0, gray_g=0.0),
     make_case("gray_absorb_hg_tau1", "gray", 3000, 1.0, "absorb", "hg", 203, gray_albedo=0.7, gray_g=-0.6),
     make_case("gray_reflect_hg_g0_tau2", "gray", 3000, 2.0, "reflect", "hg", 204, gray_albedo=0.8, gray_g=0.0),
+    # the wavelength-dependent script with one wavelength: the production kernels' own cases
+    make_case("mcu_reflect_hg_tau3", "mc", 3000, 3.0, "reflect", "hg", 301, uniform=(0.55, 0.63, 0.82, 1.3)),
+    make_case("mcu_absorb_hg_tau2", "mc", 3000, 2.0, "absorb", "hg", 302, uniform=(0.25, 0.4, 0.85, 0.8)),
+    make_case("mcu_reemit_hg_tau2", "mc", 3000, 2.0, "reemit", "hg", 303, uniform=(1.5, 0.3, 0.5, 2.0)),
+    make_case("mcu_reflect_iso_tau5", "mc", 3000, 5.0, "reflect", "iso", 304, uniform=(0.0912, 0.7, 0.6, 1.0)),
+    make_case("mcu_reflect_hg_tau30", "mc", 1500, 30.0, "reflect", "hg", 305, uniform=(0.55, 0.9, 0.95, 0.7)),
+    make_case("mcu_reflect_hg_absonly_tau1", "mc", 3000, 1.0, "reflect", "hg", 306, abs_only=1, uniform=(0.55, 0.63, 0.82, 1.3)),
+    make_case("mcu_reflect_hg_negg_tau4", "mc", 3000, 4.0, "reflect", "hg", 307, uniform=(2.0, -0.45, 0.9, 1.6)),
+    make_case("mcu_reflect_hg_tinyg_tau2", "mc", 3000, 2.0, "reflect", "hg", 308, uniform=(9.5, 3.7e-6, 0.55, 0.4)),
 ]
 
 

@@ -68,3 +68,55 @@ def test_replay_guard_on_short_stream(rt, engine):
     prm = rt.make_params(50.0, n, h=1.0)
     res, tr = engine.replay(prm, xi, np.ones(n), np.full(n, 0.5), np.ones(n), np.ones(n), np.ones(n))
     assert int(res.counts[0, rt._abi.CNT_GUARD]) == int((tr["fate"] == rt._abi.FATE_GUARD).sum()) > 0
+
+
+UNIFORM = [n for n in NAMES if n.startswith("gray_") or n.startswith("mcu_")]
+
+
+@pytest.mark.parametrize("name", UNIFORM)
+def test_production_sweep_matches_reference_where_the_streams_coincide(rt, engine, name):
+    """The cases of the golden file whose photons all carry the same constants -- the gray script's (scalar albedo and
+    g, lambda = 1; Numpy_random_walk.RunPhotons) and the wavelength-dependent script's with one wavelength (MC
+    code.py RunPhotons) -- were produced by the unmodified reference on the uniforms xi(id, j) of oracle.philox for
+    atmosphere 0 and the case's seed: exactly what the PRODUCTION sweep draws for photon ids 0..n-1 of atmosphere 0
+    under that seed on a one-wavelength table.  So the production kernels (not the replay kernel) must return the
+    reference's own numbers, with no restatement in between -- the kernel with the case's flags fixed at compile
+    time where there is one, and the run-time-flag kernel (asked for through the per-photon cosines)."""
+    c = case(name)
+    n, seed, order = int(c["n"]), int(c["seed"]), str(c["order"])
+    gray = order == "gray"
+    engine.set_tables([float(c["lam"][0])], [float(c["g"][0])], [float(c["albedo"][0])], [float(c["scale"][0])])
+    A = rt._abi
+    kw = dict(boundary=str(c["boundary"]), scatter=str(c["scatter"]), order=order, h=(1.0 if gray else rt.H_PLANCK), seed=seed,
+              abs_only=int(c["abs_only"]), n_mu_bins=10)
+    fates = np.bincount(c["ref_fate"], minlength=6)
+    kernels = set()
+    for per_photon in (False, True):
+        res = engine.run(rt.make_params(float(c["tau"]), n, escaped_mu=per_photon, **kw))
+        kernels.add(engine.last_kernel())
+        s, cnt = res.sums[0], res.counts[0].astype(np.int64)
+        np.testing.assert_allclose(s[A.SUM_INITIAL], float(c["ref_initial_momentum"]), rtol=RTOL)
+        np.testing.assert_allclose(s[A.SUM_ESCAPED], float(c["ref_escaped_momentum"]), rtol=RTOL)
+        np.testing.assert_allclose(s[A.SUM_BOUNDARY], float(c["ref_boundary_momentum"]), rtol=RTOL,
+                                   atol=1e-12 * abs(float(c["ref_initial_momentum"])))
+        assert cnt[A.CNT_ESCAPED] == fates[A.FATE_ESCAPED] and cnt[A.CNT_ESCAPED_UNCOUNTED] == fates[A.FATE_ESCAPED_UNCOUNTED]
+        assert cnt[A.CNT_ABSORBED] == fates[A.FATE_ABSORBED] and cnt[A.CNT_BOUNDARY_ABSORBED] == fates[A.FATE_BOUNDARY]
+        assert cnt[A.CNT_GUARD] == 0 and cnt[A.CNT_PHOTONS] == n
+        if int(c["ref_scatter_count"]) >= 0:
+            assert cnt[A.CNT_SCATTER] == int(c["ref_scatter_count"])
+        ref_hist = np.bincount(np.minimum(np.floor(10 * c["ref_escaped_mu"]).astype(int), 10), minlength=11)
+        assert np.array_equal(res.mu_hist[0], ref_hist)
+        if per_photon:   # the reference's escaped_mu list itself (it appends in escape order: compare as sorted lists)
+            np.testing.assert_allclose(np.sort(res.escaped_mu[0]), np.sort(c["ref_escaped_mu"]), rtol=0, atol=1e-12)
+    assert any("Runtime" in k for k in kernels), kernels
+    if name.startswith("mcu_") and not int(c["abs_only"]):   # these flag sets all have a kernel of their own
+        assert len(kernels) == 2, kernels
+
+
+def test_the_headline_kernel_is_among_them(rt, engine):
+    """mcu_reflect_hg_* run the instantiation that serves the headline sweep."""
+    c = case("mcu_reflect_hg_tau3")
+    engine.set_tables([float(c["lam"][0])], [float(c["g"][0])], [float(c["albedo"][0])], [float(c["scale"][0])])
+    engine.run(rt.make_params(float(c["tau"]), int(c["n"]), seed=int(c["seed"]), n_mu_bins=10))
+    assert engine.last_kernel() == "walk_kernel<FixedBase, false, true>"
+    assert len(UNIFORM) == 12
