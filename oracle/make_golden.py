@@ -131,8 +131,27 @@ def replay_reference(order, case):
 
 
 def make_case(name, order, n, tau, boundary, scatter, seed, abs_only=0, rand_mu0=False, gray_albedo=0.9, gray_g=0.5,
-              tiny_g=False, uniform=None):
+              tiny_g=False, uniform=None, table=None):
     rng = np.random.default_rng(seed)
+    extra = {}
+    if table is not None:
+        # A table of several wavelengths: every photon gets the constants of the wavelength the PRODUCTION sweep emits
+        # for its id under this seed (first uniform of the id's emission block through the sweep's own sampler,
+        # oracle/c_oracle.sample_indices; rand_mu: the block's second uniform is the direction), so that the
+        # reference, handed these rows, walks the histories of that sweep.
+        if os.path.dirname(HERE) not in sys.path:
+            sys.path.insert(0, os.path.dirname(HERE))
+        from oracle import c_oracle
+        wl_t, g_t, alb_t, scale_t, pdf_t = (np.asarray(v, dtype=float) for v in table)
+        ids = np.arange(n, dtype=np.uint64)
+        u_wl, u_mu = philox.block_uniforms(ids, np.uint64(0x80000000), 0, seed)
+        idx = c_oracle.sample_indices(pdf_t, u_wl)
+        lam, g, alb, scale = wl_t[idx], g_t[idx], alb_t[idx], scale_t[idx]
+        mu0 = u_mu if rand_mu0 else np.ones(n)
+        extra = dict(table_wl=wl_t, table_g=g_t, table_albedo=alb_t, table_scale=scale_t, table_pdf=pdf_t, emitted_index=idx,
+                     rand_mu=int(rand_mu0))
+        return dict(name=name, order=order, n=n, tau=float(tau), boundary=boundary, scatter=scatter, seed=int(seed),
+                    abs_only=int(abs_only), lam=lam, g=g, albedo=alb, scale=scale, mu0=mu0, extra=extra)
     if uniform is not None:  # (lambda, g, albedo, scale) the same for every photon: what a one-wavelength table gives, so
         # that a PRODUCTION sweep under the same seed walks the very same histories (tests/test_gpu_replay.py)
         lam, g, alb, scale = (np.full(n, float(v)) for v in uniform)
@@ -148,7 +167,19 @@ def make_case(name, order, n, tau, boundary, scatter, seed, abs_only=0, rand_mu0
         g, alb = np.full(n, float(gray_g)), np.full(n, float(gray_albedo))
     mu0 = rng.random(n) if rand_mu0 else np.ones(n)
     return dict(name=name, order=order, n=n, tau=float(tau), boundary=boundary, scatter=scatter, seed=int(seed),
-                abs_only=int(abs_only), lam=lam, g=g, albedo=alb, scale=scale, mu0=mu0)
+                abs_only=int(abs_only), lam=lam, g=g, albedo=alb, scale=scale, mu0=mu0, extra=extra)
+
+
+def _table(kind):
+    n = 64
+    x = np.arange(n) / (n - 1.0)
+    wl = np.round(0.1 + 0.9 * x, 4)
+    pdf = (1.0 - 0.9 * x) ** 2 / n
+    pdf[5:9] = 0.0
+    if kind == "plain":
+        return wl, (0.3 + 0.5 * x) * np.where(np.arange(n) % 7 == 0, -1, 1), 0.4 + 0.55 * x, 2.0 - 1.5 * x, pdf
+    # asymmetry parameters from 0.9 down to 1e-7, as number-weighted MRN averages give them
+    return wl, 0.9 * 10.0 ** (-7.0 * x), 0.45 + 0.5 * x, 0.5 + 1.5 * x, pdf
 
 
 REPLAY_CASES = [
@@ -175,6 +206,12 @@ REPLAY_CASES = [
     make_case("mcu_reflect_hg_absonly_tau1", "mc", 3000, 1.0, "reflect", "hg", 306, abs_only=1, uniform=(0.55, 0.63, 0.82, 1.3)),
     make_case("mcu_reflect_hg_negg_tau4", "mc", 3000, 4.0, "reflect", "hg", 307, uniform=(2.0, -0.45, 0.9, 1.6)),
     make_case("mcu_reflect_hg_tinyg_tau2", "mc", 3000, 2.0, "reflect", "hg", 308, uniform=(9.5, 3.7e-6, 0.55, 0.4)),
+    # ... and with a table of 64 wavelengths, every photon carrying the row the production sweep emits for its id
+    make_case("mct_reflect_hg_tau3", "mc", 4000, 3.0, "reflect", "hg", 401, table=_table("plain")),
+    make_case("mct_absorb_hg_tau2", "mc", 4000, 2.0, "absorb", "hg", 402, table=_table("plain")),
+    make_case("mct_reflect_iso_tau5", "mc", 4000, 5.0, "reflect", "iso", 403, table=_table("plain")),
+    make_case("mct_reflect_hg_tau0p3_randmu", "mc", 4000, 0.3, "reflect", "hg", 404, rand_mu0=True, table=_table("plain")),
+    make_case("mct_reflect_hg_tau10_smallg", "mc", 4000, 10.0, "reflect", "hg", 405, table=_table("small g")),
 ]
 
 
@@ -221,6 +258,8 @@ def main():
             out[p + k] = np.asarray(c[k])
         for k, v in res.items():
             out[p + "ref_" + k] = np.asarray(v)
+        for k, v in c["extra"].items():
+            out[p + k] = np.asarray(v)
         print(c["name"], "events", res["scatter_count"], "max draws", res["draws"].max(),
               "fates", np.bincount(res["fate"], minlength=5))
     np.savez_compressed(os.path.join(GOLDEN, "walk_replay.npz"), **out)

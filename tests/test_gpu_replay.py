@@ -120,3 +120,36 @@ def test_the_headline_kernel_is_among_them(rt, engine):
     engine.run(rt.make_params(float(c["tau"]), int(c["n"]), seed=int(c["seed"]), n_mu_bins=10))
     assert engine.last_kernel() == "walk_kernel<FixedBase, false, true>"
     assert len(UNIFORM) == 12
+
+
+TABLE = [n for n in NAMES if n.startswith("mct_")]
+
+
+@pytest.mark.parametrize("name", TABLE)
+def test_production_sweep_on_a_table_matches_reference(rt, engine, name):
+    """The same with a table of 64 wavelengths: the golden's photons carry the rows the production sweep emits for
+    their ids under the case's seed (stored as emitted_index), and the unmodified reference walked them on the sweep's
+    own uniforms.  The production sweep on that table -- emission through the alias table, record gather, walk --
+    must return the reference's numbers; with rand_mu also the direction draw of the emission block."""
+    c = case(name)
+    n, seed = int(c["n"]), int(c["seed"])
+    engine.set_tables(c["table_wl"], c["table_g"], c["table_albedo"], c["table_scale"], c["table_pdf"])
+    A = rt._abi
+    kw = dict(boundary=str(c["boundary"]), scatter=str(c["scatter"]), seed=seed, rand_mu=int(c["rand_mu"]), n_mu_bins=10)
+    fates = np.bincount(c["ref_fate"], minlength=6)
+    for per_photon in (False, True):
+        res = engine.run(rt.make_params(float(c["tau"]), n, escaped_mu=per_photon, **kw))
+        s, cnt = res.sums[0], res.counts[0].astype(np.int64)
+        np.testing.assert_allclose(s[A.SUM_INITIAL], float(c["ref_initial_momentum"]), rtol=RTOL)
+        np.testing.assert_allclose(s[A.SUM_ESCAPED], float(c["ref_escaped_momentum"]), rtol=RTOL)
+        np.testing.assert_allclose(s[A.SUM_BOUNDARY], float(c["ref_boundary_momentum"]), rtol=RTOL,
+                                   atol=1e-12 * abs(float(c["ref_initial_momentum"])))
+        assert cnt[A.CNT_SCATTER] == int(c["ref_scatter_count"])
+        assert cnt[A.CNT_ESCAPED] == fates[A.FATE_ESCAPED] and cnt[A.CNT_ESCAPED_UNCOUNTED] == fates[A.FATE_ESCAPED_UNCOUNTED]
+        assert cnt[A.CNT_ABSORBED] == fates[A.FATE_ABSORBED] and cnt[A.CNT_BOUNDARY_ABSORBED] == fates[A.FATE_BOUNDARY]
+        assert cnt[A.CNT_GUARD] == 0 and cnt[A.CNT_PHOTONS] == n
+        ref_hist = np.bincount(np.minimum(np.floor(10 * c["ref_escaped_mu"]).astype(int), 10), minlength=11)
+        assert np.array_equal(res.mu_hist[0], ref_hist)
+        if per_photon:
+            np.testing.assert_allclose(np.sort(res.escaped_mu[0]), np.sort(c["ref_escaped_mu"]), rtol=0, atol=1e-12)
+    assert len(TABLE) == 5 and len(np.unique(c["emitted_index"])) > 40
