@@ -68,7 +68,7 @@ def replay_reference(order, case):
         assert k == len(ids), (k, len(ids))
         j = st["ctr"][ids]
         st["ctr"][ids] = j + 1
-        return philox.walk_uniform(ids, j, 0, seed)
+        return (philox.walk_uniform_packed if case.get("stream") == "philox32x4" else philox.walk_uniform)(ids, j, 0, seed)
 
     mod.np = _NumpyProxy(rand)
 
@@ -131,7 +131,7 @@ def replay_reference(order, case):
 
 
 def make_case(name, order, n, tau, boundary, scatter, seed, abs_only=0, rand_mu0=False, gray_albedo=0.9, gray_g=0.5,
-              tiny_g=False, uniform=None, table=None):
+              tiny_g=False, uniform=None, table=None, stream="philox52"):
     rng = np.random.default_rng(seed)
     extra = {}
     if table is not None:
@@ -144,14 +144,16 @@ def make_case(name, order, n, tau, boundary, scatter, seed, abs_only=0, rand_mu0
         from oracle import c_oracle
         wl_t, g_t, alb_t, scale_t, pdf_t = (np.asarray(v, dtype=float) for v in table)
         ids = np.arange(n, dtype=np.uint64)
-        u_wl, u_mu = philox.block_uniforms(ids, np.uint64(0x80000000), 0, seed)
+        # (the packed stream takes the emission draw from words 0-1 of walk block 0, which no scattering precedes)
+        u_wl, u_mu = philox.block_uniforms(ids, np.uint64(0 if stream == "philox32x4" else 0x80000000), 0, seed)
+        assert not (rand_mu0 and stream == "philox32x4")
         idx = c_oracle.sample_indices(pdf_t, u_wl)
         lam, g, alb, scale = wl_t[idx], g_t[idx], alb_t[idx], scale_t[idx]
         mu0 = u_mu if rand_mu0 else np.ones(n)
-        extra = dict(table_wl=wl_t, table_g=g_t, table_albedo=alb_t, table_scale=scale_t, table_pdf=pdf_t, emitted_index=idx,
+        extra = dict(stream=stream, table_wl=wl_t, table_g=g_t, table_albedo=alb_t, table_scale=scale_t, table_pdf=pdf_t, emitted_index=idx,
                      rand_mu=int(rand_mu0))
         return dict(name=name, order=order, n=n, tau=float(tau), boundary=boundary, scatter=scatter, seed=int(seed),
-                    abs_only=int(abs_only), lam=lam, g=g, albedo=alb, scale=scale, mu0=mu0, extra=extra)
+                    abs_only=int(abs_only), lam=lam, g=g, albedo=alb, scale=scale, mu0=mu0, extra=extra, stream=stream)
     if uniform is not None:  # (lambda, g, albedo, scale) the same for every photon: what a one-wavelength table gives, so
         # that a PRODUCTION sweep under the same seed walks the very same histories (tests/test_gpu_replay.py)
         lam, g, alb, scale = (np.full(n, float(v)) for v in uniform)
@@ -166,8 +168,9 @@ def make_case(name, order, n, tau, boundary, scatter, seed, abs_only=0, rand_mu0
         lam, scale = np.ones(n), np.ones(n)
         g, alb = np.full(n, float(gray_g)), np.full(n, float(gray_albedo))
     mu0 = rng.random(n) if rand_mu0 else np.ones(n)
+    extra = dict(extra, stream=stream)
     return dict(name=name, order=order, n=n, tau=float(tau), boundary=boundary, scatter=scatter, seed=int(seed),
-                abs_only=int(abs_only), lam=lam, g=g, albedo=alb, scale=scale, mu0=mu0, extra=extra)
+                abs_only=int(abs_only), lam=lam, g=g, albedo=alb, scale=scale, mu0=mu0, extra=extra, stream=stream)
 
 
 def _table(kind):
@@ -215,6 +218,17 @@ REPLAY_CASES = [
 ]
 
 
+# The packed stream's own cases (a file of their own: the tests of walk_replay.npz rebuild the 52-bit stream)
+PACKED_CASES = [
+    make_case("mcp_reflect_hg_tau3", "mc", 3000, 3.0, "reflect", "hg", 501, uniform=(0.55, 0.63, 0.82, 1.3), stream="philox32x4"),
+    make_case("mcp_absorb_hg_tau2", "mc", 3000, 2.0, "absorb", "hg", 502, uniform=(0.25, 0.4, 0.85, 0.8), stream="philox32x4"),
+    make_case("mcp_reflect_iso_tau5", "mc", 3000, 5.0, "reflect", "iso", 503, uniform=(0.0912, 0.7, 0.6, 1.0), stream="philox32x4"),
+    make_case("grayp_reflect_hg_tau3", "gray", 3000, 3.0, "reflect", "hg", 504, gray_albedo=0.9, gray_g=0.5, stream="philox32x4"),
+    make_case("mcpt_reflect_hg_tau3", "mc", 4000, 3.0, "reflect", "hg", 505, table=_table("plain"), stream="philox32x4"),
+    make_case("mcpt_reflect_hg_tau10_smallg", "mc", 4000, 10.0, "reflect", "hg", 506, table=_table("small g"), stream="philox32x4"),
+]
+
+
 def seeded_reference(order, tau, n, boundary, scatter, seed, lam, g, alb, scale, alpha=0.3):
     if order == "mc":
         mod = ref_loader.load_mc_code()
@@ -246,6 +260,24 @@ SEEDED_CASES = [
 SEEDED_ALPHA = {"gray_reflect_draine_g0_alpha0": 0.0}
 
 
+def write_cases(cases, filename):
+    out = {"names": np.array([c["name"] for c in cases])}
+    for c in cases:
+        res = replay_reference(c["order"], c)
+        p = c["name"] + "/"
+        for k in ("order", "boundary", "scatter"):
+            out[p + k] = np.array(c[k])
+        for k in ("n", "tau", "seed", "abs_only", "lam", "g", "albedo", "scale", "mu0"):
+            out[p + k] = np.asarray(c[k])
+        for k, v in res.items():
+            out[p + "ref_" + k] = np.asarray(v)
+        for k, v in c["extra"].items():
+            out[p + k] = np.asarray(v)
+        print(c["name"], "events", res["scatter_count"], "max draws", res["draws"].max(),
+              "fates", np.bincount(res["fate"], minlength=5))
+    np.savez_compressed(os.path.join(GOLDEN, filename), **out)
+
+
 def main():
     os.makedirs(GOLDEN, exist_ok=True)
     out = {"names": np.array([c["name"] for c in REPLAY_CASES])}
@@ -263,6 +295,7 @@ def main():
         print(c["name"], "events", res["scatter_count"], "max draws", res["draws"].max(),
               "fates", np.bincount(res["fate"], minlength=5))
     np.savez_compressed(os.path.join(GOLDEN, "walk_replay.npz"), **out)
+    write_cases(PACKED_CASES, "walk_replay_packed.npz")
 
     out = {"names": np.array([c[0] for c in SEEDED_CASES])}
     for (name, order, tau, n, boundary, scatter, seed, lam, g, alb, scale) in SEEDED_CASES:

@@ -79,3 +79,33 @@ def walk_matrix(n, max_draws, atm, seed, id_base=0):
     out[:, 0::2] = ua
     out[:, 1::2] = ub
     return np.ascontiguousarray(out[:, :max_draws])
+
+
+# ---- the opt-in stream with one block per loop iteration and 32-bit uniforms (RT_RNG_PHILOX32X4) ----
+def block_words(photon_id, block, atm, seed):
+    """The four 32-bit output words of one block."""
+    pid = np.asarray(photon_id, dtype=np.uint64)
+    return philox4x32_10(pid & MASK32, pid >> np.uint64(32), block, atm, seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+
+
+def u32mid(w):
+    """One word -> (w + 1/2) / 2**32 in (0, 1), exact in float64."""
+    return (np.asarray(w, dtype=np.uint64) & MASK32).astype(np.float64) * 2.0 ** -32 + 2.0 ** -33
+
+
+def walk_uniform_packed(photon_id, j, atm, seed):
+    """Draw j of a photon's walk in the order the reference consumes them -- step, absorb, azimuth, cosine, step, ...
+    -- under the packed layout: block k holds (azimuth, cosine) of the scattering BEFORE flight k in words 0-1 and
+    (step, absorb) of flight k in words 2-3."""
+    j = np.asarray(j, dtype=np.uint64)
+    k, r = j >> np.uint64(2), j & np.uint64(3)
+    block = k + (r >= 2).astype(np.uint64)
+    w = block_words(photon_id, block, atm, seed)
+    word = np.where(r == 0, w[2], np.where(r == 1, w[3], np.where(r == 2, w[0], w[1])))
+    return u32mid(word)
+
+
+def walk_matrix_packed(n, max_draws, atm, seed, id_base=0):
+    ids = (np.arange(n, dtype=np.uint64) + np.uint64(id_base))[:, None]
+    j = np.arange(max_draws, dtype=np.uint64)[None, :]
+    return np.ascontiguousarray(walk_uniform_packed(ids, j, atm, seed))

@@ -183,3 +183,31 @@ def test_packed_stream_of_the_oracle(c_oracle):
     fa = (a.sums[:, 0] - a.sums[:, 1] + a.sums[:, 2]) / a.sums[:, 0]
     fb = (b.sums[:, 0] - b.sums[:, 1] + b.sums[:, 2]) / b.sums[:, 0]
     np.testing.assert_allclose(fa, fb, rtol=0.03)
+
+
+PACKED = np.load(os.path.join(os.path.dirname(__file__), "golden", "walk_replay_packed.npz"))
+
+
+@pytest.mark.parametrize("name", [str(n) for n in PACKED["names"]])
+def test_c_oracle_packed_production_matches_reference(c_oracle, name):
+    """The one-block stream (rng='philox32x4') of the C restatement in PRODUCTION mode against the unmodified
+    reference run on that stream's uniforms (oracle/philox.walk_uniform_packed): the golden's photons carry the
+    constants the sweep gives them, so the sweep must return the reference's own numbers."""
+    c = {k.split("/", 1)[1]: PACKED[k] for k in PACKED.files if k.startswith(name + "/")}
+    n, order = int(c["n"]), str(c["order"])
+    if "table_wl" in c:
+        tab = (c["table_wl"], c["table_g"], c["table_albedo"], c["table_scale"], c["table_pdf"])
+    else:
+        tab = ([float(c["lam"][0])], [float(c["g"][0])], [float(c["albedo"][0])], [float(c["scale"][0])])
+    prm = c_oracle.make_params(float(c["tau"]), n, boundary=str(c["boundary"]), scatter=str(c["scatter"]), order=order,
+                               h=(1.0 if order == "gray" else 6.6261e-27), seed=int(c["seed"]), rng="philox32x4", n_mu_bins=10)
+    res = c_oracle.run(prm, *tab)
+    fates = np.bincount(c["ref_fate"], minlength=6)
+    cnt = res.counts[0].astype(np.int64)
+    assert cnt[1] == fates[1] and cnt[2] == fates[2] and cnt[3] == fates[3] and cnt[4] == fates[4] and cnt[6] == 0
+    if int(c["ref_scatter_count"]) >= 0:
+        assert cnt[0] == int(c["ref_scatter_count"])
+    np.testing.assert_allclose(res.sums[0, 0], float(c["ref_initial_momentum"]), rtol=1e-12)
+    np.testing.assert_allclose(res.sums[0, 1], float(c["ref_escaped_momentum"]), rtol=1e-12)
+    np.testing.assert_allclose(res.sums[0, 2], float(c["ref_boundary_momentum"]), rtol=1e-12,
+                               atol=1e-12 * abs(float(c["ref_initial_momentum"])))
