@@ -107,16 +107,32 @@ def replay_reference(order, case):
     if order == "mc":
         created = dict(first=True)
 
+        ex = case.get("extra", {})
+        n_emitted = np.ones(n, dtype=np.uint64)  # emission blocks used so far, per photon
+
         def create(num, init, *rest):
-            ids = np.arange(n) if created["first"] else st["reemit_ids"]
+            first = created["first"]
+            ids = np.arange(n) if first else st["reemit_ids"]
             created["first"] = False
             assert len(ids) == num
             ps = np.array([init, ] * num, dtype=float)
-            ps[:, 4] = mu0[ids]
-            ps[:, 5] = lam[ids]
-            ps[:, 6] = g[ids]
-            ps[:, 7] = alb[ids]
-            ps[:, 8] = scale[ids]
+            if first or "table_wl" not in ex:
+                ps[:, 4] = mu0[ids]
+                ps[:, 5] = lam[ids]
+                ps[:, 6] = g[ids]
+                ps[:, 7] = alb[ids]
+                ps[:, 8] = scale[ids]
+            else:
+                # re-emission on a table: the rows the production sweep emits from the photon's NEXT emission block
+                from oracle import c_oracle
+                u_wl, u_mu = philox.block_uniforms(ids.astype(np.uint64), np.uint64(0x80000000) + n_emitted[ids], 0, seed)
+                n_emitted[ids] += np.uint64(1)
+                idx = c_oracle.sample_indices(ex["table_pdf"], u_wl)
+                ps[:, 4] = u_mu if ex["rand_mu"] else 1.0
+                ps[:, 5] = ex["table_wl"][idx]
+                ps[:, 6] = ex["table_g"][idx]
+                ps[:, 7] = ex["table_albedo"][idx]
+                ps[:, 8] = ex["table_scale"][idx]
             return ps
 
         mod.CreatePhotons = create
@@ -229,6 +245,15 @@ PACKED_CASES = [
 ]
 
 
+# Re-emission at the floor on a table: the re-emitted photon draws a new wavelength (and direction) from its next
+# emission block, so these cases have no fixed per-photon constants and only the production sweeps are compared with them.
+REEMIT_TABLE_CASES = [
+    make_case("mct_reemit_hg_tau2", "mc", 4000, 2.0, "reemit", "hg", 601, table=_table("plain")),
+    make_case("mct_reemit_hg_tau4_randmu", "mc", 4000, 4.0, "reemit", "hg", 602, rand_mu0=True, table=_table("plain")),
+    make_case("mct_reemit_iso_tau1", "mc", 4000, 1.0, "reemit", "iso", 603, table=_table("small g")),
+]
+
+
 def seeded_reference(order, tau, n, boundary, scatter, seed, lam, g, alb, scale, alpha=0.3):
     if order == "mc":
         mod = ref_loader.load_mc_code()
@@ -296,6 +321,7 @@ def main():
               "fates", np.bincount(res["fate"], minlength=5))
     np.savez_compressed(os.path.join(GOLDEN, "walk_replay.npz"), **out)
     write_cases(PACKED_CASES, "walk_replay_packed.npz")
+    write_cases(REEMIT_TABLE_CASES, "walk_reemit_table.npz")
 
     out = {"names": np.array([c[0] for c in SEEDED_CASES])}
     for (name, order, tau, n, boundary, scatter, seed, lam, g, alb, scale) in SEEDED_CASES:

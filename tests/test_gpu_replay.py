@@ -153,3 +153,33 @@ def test_production_sweep_on_a_table_matches_reference(rt, engine, name):
         if per_photon:
             np.testing.assert_allclose(np.sort(res.escaped_mu[0]), np.sort(c["ref_escaped_mu"]), rtol=0, atol=1e-12)
     assert len(TABLE) == 5 and len(np.unique(c["emitted_index"])) > 40
+
+
+GR = np.load(os.path.join(GOLDEN, "walk_reemit_table.npz"))
+
+
+@pytest.mark.parametrize("name", [str(n) for n in GR["names"]])
+def test_production_sweep_with_reemission_on_a_table_matches_reference(rt, engine, name):
+    """boundary='reemit' on a table of 64 wavelengths: a photon that reaches the floor is replaced by a fresh
+    CreatePhotons row (MC code.py:539-547) -- a new wavelength and, with rand_mu, a new direction, which the sweep
+    draws from the photon's next emission block.  The golden holds the unmodified reference handed exactly those rows
+    (oracle/make_golden.py), so the sweep's second emission inside a flight is pinned to the reference as well."""
+    c = {k.split("/", 1)[1]: GR[k] for k in GR.files if k.startswith(name + "/")}
+    n = int(c["n"])
+    engine.set_tables(c["table_wl"], c["table_g"], c["table_albedo"], c["table_scale"], c["table_pdf"])
+    A = rt._abi
+    fates = np.bincount(c["ref_fate"], minlength=6)
+    for per_photon in (False, True):
+        res = engine.run(rt.make_params(float(c["tau"]), n, boundary="reemit", scatter=str(c["scatter"]), seed=int(c["seed"]),
+                                        rand_mu=int(c["rand_mu"]), n_mu_bins=10, escaped_mu=per_photon))
+        s, cnt = res.sums[0], res.counts[0].astype(np.int64)
+        np.testing.assert_allclose(s[A.SUM_INITIAL], float(c["ref_initial_momentum"]), rtol=RTOL)
+        np.testing.assert_allclose(s[A.SUM_ESCAPED], float(c["ref_escaped_momentum"]), rtol=RTOL)
+        np.testing.assert_allclose(s[A.SUM_BOUNDARY], float(c["ref_boundary_momentum"]), rtol=RTOL,
+                                   atol=1e-12 * abs(float(c["ref_initial_momentum"])))
+        assert cnt[A.CNT_SCATTER] == int(c["ref_scatter_count"])
+        assert cnt[A.CNT_ESCAPED] == fates[A.FATE_ESCAPED] and cnt[A.CNT_ESCAPED_UNCOUNTED] == fates[A.FATE_ESCAPED_UNCOUNTED]
+        assert cnt[A.CNT_ABSORBED] == fates[A.FATE_ABSORBED] and cnt[A.CNT_GUARD] == 0 and cnt[A.CNT_PHOTONS] == n
+        assert cnt[A.CNT_REEMITTED] > 50
+        ref_hist = np.bincount(np.minimum(np.floor(10 * c["ref_escaped_mu"]).astype(int), 10), minlength=11)
+        assert np.array_equal(res.mu_hist[0], ref_hist)

@@ -211,3 +211,24 @@ def test_c_oracle_packed_production_matches_reference(c_oracle, name):
     np.testing.assert_allclose(res.sums[0, 1], float(c["ref_escaped_momentum"]), rtol=1e-12)
     np.testing.assert_allclose(res.sums[0, 2], float(c["ref_boundary_momentum"]), rtol=1e-12,
                                atol=1e-12 * abs(float(c["ref_initial_momentum"])))
+
+
+REEMIT_TABLE = np.load(os.path.join(os.path.dirname(__file__), "golden", "walk_reemit_table.npz"))
+
+
+@pytest.mark.parametrize("name", [str(n) for n in REEMIT_TABLE["names"]])
+def test_c_oracle_reemission_on_a_table_matches_reference(c_oracle, name):
+    """boundary='reemit' with a table: the re-emitted photon's new row comes from its next emission block; the golden is
+    the unmodified reference handed those rows (oracle/make_golden.py)."""
+    c = {k.split("/", 1)[1]: REEMIT_TABLE[k] for k in REEMIT_TABLE.files if k.startswith(name + "/")}
+    prm = c_oracle.make_params(float(c["tau"]), int(c["n"]), boundary="reemit", scatter=str(c["scatter"]), seed=int(c["seed"]),
+                               rand_mu=int(c["rand_mu"]), n_mu_bins=10)
+    res = c_oracle.run(prm, c["table_wl"], c["table_g"], c["table_albedo"], c["table_scale"], c["table_pdf"])
+    fates = np.bincount(c["ref_fate"], minlength=6)
+    cnt = res.counts[0].astype(np.int64)
+    assert cnt[0] == int(c["ref_scatter_count"]) and cnt[1] == fates[1] and cnt[2] == fates[2] and cnt[3] == fates[3]
+    assert cnt[5] > 50 and cnt[6] == 0
+    np.testing.assert_allclose(res.sums[0, 0], float(c["ref_initial_momentum"]), rtol=1e-12)
+    np.testing.assert_allclose(res.sums[0, 1], float(c["ref_escaped_momentum"]), rtol=1e-12)
+    np.testing.assert_allclose(res.sums[0, 2], float(c["ref_boundary_momentum"]), rtol=1e-12,
+                               atol=1e-12 * abs(float(c["ref_initial_momentum"])))
