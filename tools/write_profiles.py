@@ -25,7 +25,7 @@ def summary(path):
 def val(lines, name):
     for l in lines:
         if l.startswith("| " + name + " "):
-            return float(l.split("|")[2])
+            return float(l.split("|")[4])  # per dispatch: a counter collected in several passes has several dispatches
     raise KeyError(name)
 
 
