@@ -1,4 +1,6 @@
-"""GPU parity, replay mode: the HIP walk on pre-drawn uniforms vs the reference's own outputs.
+"""GPU parity against the reference's own outputs: the HIP walk on pre-drawn uniforms (replay mode), and the
+PRODUCTION sweeps wherever the reference was run on exactly the uniforms and photon rows a sweep produces
+(cases gray_*, mcu_*, mct_* and the file walk_reemit_table.npz; see the tests below).
 
 tests/golden/walk_replay.npz holds what the UNMODIFIED reference functions returned
 (RunPhotons, MC code.py:620-779 and Numpy_random_walk.py:280-408) when every photon consumed
