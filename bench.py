@@ -250,7 +250,7 @@ def main():
                              n_mu_bins=N_MU_BINS, n_slabs=n_slabs, rank=rank, world=world, h=cfg["h"],
                              monochromatic=cfg["monochromatic"], photon_id_base=i * total_photons, rng=args.rng,
                              table_of_atm=cfg.get("table_of_atm"))
-        eng.run_device(prm, *buf.pointers(), None, stream)
+        eng.run_device(prm, *buf.pointers(), stream)
         buf.all_reduce()  # the step's only collective: every slab entry is non-zero on exactly one rank
         # scatter events of this step (whole job after the all-reduce), kept on the device
         return buf.counts.view(n_atm, A.NCNT)[:, A.CNT_SCATTER].sum()

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 7
+#define RT_ABI_VERSION 8
 
 typedef enum rt_status {
     RT_OK = 0,
@@ -135,7 +135,18 @@ enum {
  *   more than one block per iteration). */
 enum rt_rng_mode { RT_RNG_PHILOX52 = 0, RT_RNG_PHILOX32X4 = 1 };
 
+/* rt_params.flags */
+enum {
+    RT_FLAG_RUNTIME_KERNEL = 1u /* walk with the kernel that reads every option at run time even where an instantiation
+                                   with the sweep's options fixed at compile time exists (both give the same bits;
+                                   for testing one against the other) */
+};
+
 typedef struct rt_params {
+    uint32_t struct_size;          /* = sizeof(rt_params) of the header the caller was built against.  Every entry point
+                                      that takes an rt_params refuses any other value with RT_ERR_INVALID before it reads
+                                      another member: a binding typed from an older header (a shorter struct) cannot make
+                                      the library read past the caller's object. */
     int32_t n_atm;
     int32_t boundary;              /* RT_BOUNDARY_* ; reference flag `boundary`, MC code.py:78 */
     int32_t scatter;               /* RT_SCATTER_*  ; reference flag `scatter`,  MC code.py:81 */
@@ -150,6 +161,7 @@ typedef struct rt_params {
     int32_t n_slabs;               /* fixed partition of every atmosphere's photon-id range (default 8) */
     int32_t rank;                  /* this context walks slabs s with s % world == rank */
     int32_t world;
+    uint32_t flags;                /* RT_FLAG_* bits, 0 by default */
     uint64_t seed;                 /* Philox key */
     uint64_t photon_id_base;       /* added to every photon id (independent repeat runs) */
     double monochromatic_wl;       /* reference global `monochromatic`, MC code.py:88, :387-391; 0 = sample the table */
@@ -179,7 +191,9 @@ typedef struct rt_tallies {
     uint64_t* mu_hist;     /* [n_atm][n_mu_bins + 1] escape cosines: second-test population for
                               RT_ORDER_MC (MC code.py:693), the single test for RT_ORDER_GRAY */
     double* depth_momentum; /* [n_atm][n_depth_bins] dust momentum deposition by depth z / (tau*Scale) */
-    double* depth_energy;   /* [n_atm][n_depth_bins] absorbed w*h by depth */
+    double* depth_energy;   /* [n_atm][n_depth_bins] absorbed w*h by depth.  Both are added per chunk of photon ids by
+                               the wave that walks it, then per slab in chunk order, then over the slabs in index
+                               order: bit for bit reproducible and independent of the number of GPUs, like `sums` */
     double* slab_sums;     /* [n_atm][n_slabs][RT_NSUM] per-slab partial sums (zero for slabs of other ranks);
                               summing the slab axis in index order gives `sums` bit for bit on any GPU count */
 } rt_tallies;
@@ -230,15 +244,18 @@ int rt_run(rt_ctx* ctx, const rt_params* p, rt_tallies* out);
 
 /* Same sweep, results left on the device for a collective:
  * d_slab_sums  [n_atm][n_slabs][RT_NSUM] doubles, d_counts [n_atm][RT_NCNT] u64,
- * d_mu_hist [n_atm][n_mu_bins+1] u64, d_depth [2][n_atm][n_depth_bins] doubles (may be NULL when
- * n_depth_bins == 0).  Buffers are overwritten (every entry: this rank's share, zeros for the slabs of other ranks). The work
+ * d_mu_hist [n_atm][n_mu_bins+1] u64, d_slab_depth [n_atm][n_slabs][2][n_depth_bins] doubles (momentum bins, then
+ * energy bins, of every slab; may be NULL when n_depth_bins == 0).  Buffers are overwritten (every entry: this rank's
+ * share, zeros for the slabs of other ranks); summing the slab axis in index order gives rt_run's sums / depth_momentum /
+ * depth_energy, with the same bits on any number of GPUs.  The work
  * is enqueued on `stream` (a hipStream_t passed as void*; NULL = default stream) and NOT synchronised.
- * A context owns one block of device work memory (plan, work queue, tally copies, chunk partial sums; it grows on
- * demand, so a call may allocate): successive calls on one
+ * A context owns one block of device work memory (plan, work queue, tally copies, and per chunk of photon ids the ten
+ * partial sums and 2 * n_depth_bins depth bins; it grows on demand, so a call may allocate; RT_ERR_LIMIT beyond
+ * 64 GiB): successive calls on one
  * context must go to the same stream, or the caller orders them itself (event or synchronise) -- two
  * sweeps of one context in flight on different streams race.  Use one context per concurrent stream. */
 int rt_run_device(rt_ctx* ctx, const rt_params* p, void* d_slab_sums, void* d_counts, void* d_mu_hist,
-                  void* d_depth, void* stream);
+                  void* d_slab_depth, void* stream);
 
 /* The same sweep for callers that cannot allocate: tight serving loops, harnesses that forbid hipMalloc, code that
  * must not disturb the allocator (e.g. while another stream is being captured into a HIP graph).  No counterpart in
@@ -249,13 +266,13 @@ int rt_run_device(rt_ctx* ctx, const rt_params* p, void* d_slab_sums, void* d_co
  * after the plan upload and waits for the previous call's before it reuses the staging buffer.)
  * Limits (RT_ERR_LIMIT beyond them, before anything is enqueued): n_atm <= 4096, and the work memory within the
  * array: 60 * n_atm bytes of plan, up to 8 MiB of tally copies (8 * n_atm * (RT_NCNT + n_mu_bins + 1) bytes each, as
- * many as fit, at most 64) and 80 bytes per chunk of this rank's slabs (a chunk is 8192 photon ids for slabs of at
- * least 250 000 ids, shorter below) <= 33554432 bytes in all -- the headline sweep (100 atmospheres x 2e7 photons on
+ * many as fit, at most 64) and 80 + 16 * n_depth_bins bytes per chunk of this rank's slabs (a chunk is 8192 photon ids
+ * for slabs of at least 250 000 ids, shorter below) <= 33554432 bytes in all -- the headline sweep (100 atmospheres x 2e7 photons on
  * one GPU: 244 800 chunks) needs 21 MB of it.  rt_set_tables must have been called before (that call allocates).
  * All contexts of one GPU share the array: two static sweeps in flight on one GPU at the same time, on whatever
  * streams or contexts, race; successive calls on one stream are ordered and need no clearing by the caller. */
 int rt_run_device_static(rt_ctx* ctx, const rt_params* p, void* d_slab_sums, void* d_counts, void* d_mu_hist,
-                         void* d_depth, void* stream);
+                         void* d_slab_depth, void* stream);
 
 /* ---- the collective, for callers without a Python runtime (one process per GPU) ----
  * No counterpart in the reference (single process).  RCCL is opened at run time by these calls (librccl.so.1; a
@@ -267,17 +284,28 @@ int rt_run_device_static(rt_ctx* ctx, const rt_params* p, void* d_slab_sums, voi
  *   rt_run_allreduce   rt_run_device for the slabs of this process's rank (rank / world of the communicator replace
  *                      p->rank / p->world; n_slabs must be a multiple of world) followed by ONE all-reduce on the
  *                      same stream, not synchronised.  d_tallies is one device buffer of 64-bit words,
- *                          [n_atm][n_slabs][RT_NSUM] doubles | [n_atm][RT_NCNT] u64 | [n_atm][n_mu_bins + 1] u64,
+ *                          [n_atm][n_slabs][RT_NSUM] doubles | [n_atm][RT_NCNT] u64 | [n_atm][n_mu_bins + 1] u64 |
+ *                          [n_atm][n_slabs][2][n_depth_bins] doubles,
  *                      summed as 64-bit integers: every slab entry is non-zero on exactly one rank and zero bits on
  *                      the others, so the doubles come back unchanged, and summing the slab axis in index order
- *                      gives the same bits on any number of GPUs.  With n_depth_bins > 0, d_depth
- *                      ([2][n_atm][n_depth_bins] doubles) gets a second, floating-point all-reduce.
+ *                      gives the same bits on any number of GPUs (depth bins included).
+ *                      A non-zero return on one process (a refused argument, a failed allocation or launch) is that
+ *                      process's alone: its peers are already waiting in the collective, so the caller must end the
+ *                      job on every rank; the communicator is not usable afterwards.
  *   rt_comm_destroy    leaves the communicator (rt_destroy does it too). */
 #define RT_COMM_ID_BYTES 128
 int rt_comm_unique_id(void* id);
 int rt_comm_init(rt_ctx* ctx, int rank, int world, const void* id);
 int rt_comm_destroy(rt_ctx* ctx);
-int rt_run_allreduce(rt_ctx* ctx, const rt_params* p, void* d_tallies, void* d_depth, void* stream);
+int rt_run_allreduce(rt_ctx* ctx, const rt_params* p, void* d_tallies, void* stream);
+
+/* The wavelengths the sweeps emit, photon by photon: for photon ids [first_id, first_id + n) of atmosphere `atm`
+ * (its index in p->tau_atm) under p's seed, photon_id_base, rng_mode, monochromatic_wl and table_of_atm, out_index[i]
+ * is the index into wl[] that CreatePhotons' wavelength draw (AcceptReject, MC code.py:239-268, :389-394) is replaced
+ * by, and out_mu0[i] (may be NULL) the starting cosine (rand_mu, MC code.py:384-385).  Host arrays; n <= 2^31.
+ * For comparing the emission law with the reference's and for rebuilding what a sweep walked. */
+int rt_emission_indices(rt_ctx* ctx, const rt_params* p, int32_t atm, uint64_t first_id, int64_t n, int32_t* out_index,
+                        double* out_mu0);
 
 /* Replay: photon i consumes xi[i*max_draws + j], j = 0,1,... instead of Philox, with its constants
  * given directly (what CreatePhotons would have put in its row).  Used to compare trajectories with
@@ -356,7 +384,8 @@ typedef struct rt_shell_galaxy {
 typedef struct rt_shell_model {
     int32_t aging;           /* stellar_aging */
     int32_t static_momentum; /* MC code.py:119 */
-    int32_t n_tau, n_age, n_lage, pad_;
+    int32_t n_tau, n_age, n_lage;
+    uint32_t struct_size;    /* = sizeof(rt_shell_model); any other value is refused with RT_ERR_INVALID */
     double G, c, sigma_sb, year_s; /* cgs; year_s = 31556952 (MC code.py:943) */
     double h_hi_cm;                /* h_Hi * cm_pc */
     double r_escape;               /* 10000 * cm_pc */

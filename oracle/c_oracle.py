@@ -42,11 +42,13 @@ def make_params(tau, n_photons, *, boundary="reflect", scatter="hg", order="mc",
                 geometry="slab", shell_inner=0.0):
     tau = np.ascontiguousarray(np.atleast_1d(tau), dtype=np.float64)
     npn = np.ascontiguousarray(np.broadcast_to(np.atleast_1d(n_photons), tau.shape), dtype=np.uint64)
-    p = abi.RtParams(len(tau), abi.BOUNDARY[boundary], abi.SCATTER[scatter], abi.ORDER[order], int(rand_mu),
-                     int(abs_only), int(n_mu_bins), int(n_depth_bins), int(max_events), int(n_slabs), int(rank),
-                     int(world), int(seed), int(photon_id_base), float(monochromatic), float(alpha), float(h),
-                     _dp(tau), npn.ctypes.data_as(abi.c_u64_p), abi.RNG[rng], abi.GEOMETRY[geometry],
-                     None, float(shell_inner))
+    p = abi.RtParams(struct_size=C.sizeof(abi.RtParams), n_atm=len(tau), boundary=abi.BOUNDARY[boundary],
+                     scatter=abi.SCATTER[scatter], loop_order=abi.ORDER[order], rand_mu=int(rand_mu), abs_only=int(abs_only),
+                     n_mu_bins=int(n_mu_bins), n_depth_bins=int(n_depth_bins), max_events_per_photon=int(max_events),
+                     n_slabs=int(n_slabs), rank=int(rank), world=int(world), seed=int(seed),
+                     photon_id_base=int(photon_id_base), monochromatic_wl=float(monochromatic), alpha=float(alpha),
+                     h=float(h), tau_atm=_dp(tau), n_photons=npn.ctypes.data_as(abi.c_u64_p), rng_mode=abi.RNG[rng],
+                     geometry=abi.GEOMETRY[geometry], shell_inner=float(shell_inner))
     p._keep = (tau, npn)
     if table_of_atm is not None:
         tab = np.ascontiguousarray(np.broadcast_to(np.atleast_1d(table_of_atm), tau.shape), dtype=np.int32)

@@ -11,13 +11,14 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "csrc", "librt_amd.so")
 
-RT_ABI_VERSION = 7
+RT_ABI_VERSION = 8
 
 BOUNDARY = {"reflect": 0, "absorb": 1, "reemit": 2}
 SCATTER = {"hg": 0, "iso": 1, "draine": 2, "draine_exact": 3}
 GEOMETRY = {"slab": 0, "shell": 1}
 ORDER = {"mc": 0, "gray": 1}
 RNG = {"philox52": 0, "philox32x4": 1}
+FLAG_RUNTIME_KERNEL = 1
 
 FATE_ESCAPED, FATE_ESCAPED_UNCOUNTED, FATE_ABSORBED, FATE_BOUNDARY, FATE_GUARD = 1, 2, 3, 4, 5
 
@@ -34,9 +35,11 @@ c_u64_p = C.POINTER(C.c_uint64)
 
 class RtParams(C.Structure):
     _fields_ = [
+        ("struct_size", C.c_uint32),
         ("n_atm", C.c_int32), ("boundary", C.c_int32), ("scatter", C.c_int32), ("loop_order", C.c_int32),
         ("rand_mu", C.c_int32), ("abs_only", C.c_int32), ("n_mu_bins", C.c_int32), ("n_depth_bins", C.c_int32),
         ("max_events_per_photon", C.c_int32), ("n_slabs", C.c_int32), ("rank", C.c_int32), ("world", C.c_int32),
+        ("flags", C.c_uint32),
         ("seed", C.c_uint64), ("photon_id_base", C.c_uint64),
         ("monochromatic_wl", C.c_double), ("alpha", C.c_double), ("h", C.c_double),
         ("tau_atm", c_double_p), ("n_photons", c_u64_p),
@@ -70,7 +73,7 @@ class RtShellGalaxy(C.Structure):
 
 
 class RtShellModel(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("aging", "static_momentum", "n_tau", "n_age", "n_lage", "pad_")] \
+    _fields_ = [(n, C.c_int32) for n in ("aging", "static_momentum", "n_tau", "n_age", "n_lage")] + [("struct_size", C.c_uint32)] \
              + [(n, C.c_double) for n in ("G", "c", "sigma_sb", "year_s", "h_hi_cm", "r_escape", "time_slice",
                                           "tau_cutoff", "l_norm")] \
              + [(n, c_double_p) for n in ("mc_tau", "mc_age", "mc_val", "l_age", "l_val", "ratio_val")] \
@@ -105,7 +108,7 @@ class RtPhotonTrace(C.Structure):
 EXPORTS = ["rt_abi_version", "rt_last_error", "rt_create", "rt_destroy", "rt_device_info", "rt_set_tables",
            "rt_run", "rt_run_device", "rt_replay", "rt_kernel_time", "rt_selftest_math", "rt_build_grain_tables",
            "rt_shell_velocity", "rt_shell_rhs", "rt_set_tables_multi", "rt_run_device_static", "rt_last_kernel",
-           "rt_comm_unique_id", "rt_comm_init", "rt_comm_destroy", "rt_run_allreduce"]
+           "rt_comm_unique_id", "rt_comm_init", "rt_comm_destroy", "rt_run_allreduce", "rt_emission_indices"]
 
 _lib = None
 
@@ -136,7 +139,8 @@ def load_library(path=None):
     lib.rt_comm_unique_id.argtypes = [vp]
     lib.rt_comm_init.argtypes = [vp, C.c_int, C.c_int, vp]
     lib.rt_comm_destroy.argtypes = [vp]
-    lib.rt_run_allreduce.argtypes = [vp, C.POINTER(RtParams), vp, vp, vp]
+    lib.rt_run_allreduce.argtypes = [vp, C.POINTER(RtParams), vp, vp]
+    lib.rt_emission_indices.argtypes = [vp, C.POINTER(RtParams), C.c_int32, C.c_uint64, C.c_int64, C.POINTER(C.c_int32), c_double_p]
     lib.rt_replay.argtypes = [vp, C.POINTER(RtParams), C.c_int64, C.c_int32, c_double_p, c_double_p, c_double_p,
                               c_double_p, c_double_p, c_double_p, C.POINTER(RtTallies), C.POINTER(RtPhotonTrace)]
     lib.rt_build_grain_tables.argtypes = [vp, C.POINTER(RtGrainSet), C.c_double, C.c_double, C.c_double, C.c_int32,

@@ -96,10 +96,10 @@ struct rt_ctx {
     hipEvent_t staged = nullptr;
     bool staged_pending = false;
     // result staging for rt_run / rt_replay
-    DevBuf<double> d_slab_sums, d_depth, d_sums;
+    DevBuf<double> d_slab_sums, d_depth, d_sums;  // d_depth: [n_atm][n_slabs][2][n_depth_bins] (rt_run), [2][n_depth_bins] (rt_replay)
     DevBuf<unsigned long long> d_counts, d_mu_hist;
-    int blocks_per_cu[rt::kWalkVariants] = {};  // occupancy of each walk-kernel variant for blocks_lds bytes of LDS
-    size_t blocks_lds[rt::kWalkVariants] = {};
+    std::vector<int> blocks_per_cu;  // occupancy of each walk-kernel variant for blocks_lds bytes of LDS (0: not yet asked)
+    std::vector<size_t> blocks_lds;
     int last_variant = -1;  // the variant the last sweep ran (rt_last_kernel)
     // the collective (rt_comm_init): one RCCL communicator per context, rank and size as given there
     ncclComm_t comm = nullptr;
@@ -115,7 +115,12 @@ namespace {
 
 int check_common(const rt_params* p) {
     if (!p) return fail(RT_ERR_INVALID, "params is NULL");
+    if (p->struct_size != sizeof(rt_params))  // before any other member is read: a shorter struct ends before them
+        return fail(RT_ERR_INVALID,
+                    "rt_params.struct_size is %u, but this library's rt_params has %zu bytes (ABI %d): the caller's binding "
+                    "was typed from another version of include/rt_amd.h", p->struct_size, sizeof(rt_params), RT_ABI_VERSION);
     if (p->n_atm < 1) return fail(RT_ERR_INVALID, "n_atm must be >= 1 (got %d)", p->n_atm);
+    if (p->flags & ~(uint32_t)RT_FLAG_RUNTIME_KERNEL) return fail(RT_ERR_INVALID, "unknown bits in flags (%#x)", p->flags);
     if (!p->tau_atm || !p->n_photons) return fail(RT_ERR_INVALID, "tau_atm / n_photons is NULL");
     if (p->boundary < 0 || p->boundary > 2)
         return fail(RT_ERR_INVALID, "No valid boundary condition specified (boundary=%d)", p->boundary);
@@ -181,6 +186,19 @@ rt::Cfg make_cfg(const rt_ctx* ctx, const rt_params* p) {
     return c;
 }
 
+// CreatePhotons rounds the wavelength to 4 decimals and joins on exact equality (MC code.py:394,403-404).
+int find_monochromatic(const rt_ctx* ctx, double wl, int32_t* index) {
+    const double want = std::round(wl * 1e4) / 1e4;
+    for (int i = 0; i < ctx->n_wl; ++i)
+        if (ctx->wl[i] == want || ctx->wl[i] == wl) {
+            *index = i;
+            return RT_OK;
+        }
+    return fail(RT_ERR_INVALID,
+                "monochromatic wavelength %.6g has no exact match in the table (the reference would loop forever on NaN "
+                "constants)", wl);
+}
+
 // Chunk length as a function of the atmosphere's slab length and optical depth only, never of the number of
 // ranks, so that the chunk partial sums -- and with them every result bit -- are the same for any number of GPUs.
 struct ChunkRule {
@@ -225,26 +243,29 @@ void drain_events(rt_ctx* ctx) {
 }
 
 
-// Which instantiation of the walk kernel serves a sweep: one with the sweep's flags fixed at compile time where there
-// is one, else the kernel that reads every flag at run time.
-rt::WalkVariant pick_variant(const rt_params* p, const rt::Cfg& cfg) {
-    const bool packed = p->rng_mode == RT_RNG_PHILOX32X4;
-    const bool slab = p->geometry == RT_GEOM_SLAB && !p->abs_only && !p->escaped_mu;
-    const bool mc = p->loop_order == RT_ORDER_MC, reflect = p->boundary == RT_BOUNDARY_REFLECT, hg = p->scatter == RT_SCATTER_HG;
-    const bool depth = p->n_depth_bins > 0;
-    if (slab && mc && reflect && hg && !depth) {
-        const bool plain = !p->rand_mu && cfg.mono_index < 0;  // the reference's defaults throughout
-        if (packed) return plain ? rt::kWalkPlainPacked : rt::kWalkBasePacked;
-        return plain ? rt::kWalkPlain : rt::kWalkBase;
+// Which instantiation of the walk kernel serves a sweep: the one with exactly the sweep's flags fixed at compile time
+// where there is one, else the kernel that reads every flag at run time.
+int pick_variant(const rt_params* p, const rt::Cfg& cfg) {
+    const int runtime = p->rng_mode == RT_RNG_PHILOX32X4 ? rt::kWalkRuntimePacked : rt::kWalkRuntime;
+    if (p->flags & RT_FLAG_RUNTIME_KERNEL) return runtime;
+    rt::WalkKey k;
+    k.order = p->loop_order;
+    k.boundary = p->boundary;
+    k.law = p->scatter;
+    k.depth = p->n_depth_bins > 0;
+    k.abs_only = p->abs_only != 0;
+    k.shell = p->geometry == RT_GEOM_SHELL;
+    k.emu = p->escaped_mu != nullptr;
+    k.rng = p->rng_mode;
+    k.plain = false;
+    if (!p->rand_mu && cfg.mono_index < 0) {  // the reference's defaults throughout: a kernel without their selects
+        k.plain = true;
+        const int v = rt::walk_find_variant(k);
+        if (v >= 0) return v;
+        k.plain = false;
     }
-    if (slab && !packed) {
-        if (mc && reflect && hg && depth) return rt::kWalkDepth;
-        if (mc && hg && !depth && p->boundary == RT_BOUNDARY_ABSORB) return rt::kWalkAbsorb;
-        if (mc && hg && !depth && p->boundary == RT_BOUNDARY_REEMIT) return rt::kWalkReemit;
-        if (mc && reflect && !depth && p->scatter == RT_SCATTER_ISO) return rt::kWalkIso;
-        if (!mc && reflect && hg && !depth) return rt::kWalkGray;
-    }
-    return packed ? rt::kWalkRuntimePacked : rt::kWalkRuntime;
+    const int v = rt::walk_find_variant(k);
+    return v >= 0 ? v : runtime;
 }
 
 // Device work memory of one sweep, one block of bytes:
@@ -252,8 +273,9 @@ rt::WalkVariant pick_variant(const rt_params* p, const rt::Cfg& cfg) {
 //   [queue counter, 256 bytes]                                    zeroed per sweep
 //   [tally copies: n_copies x n_atm x (RT_NCNT + n_mu_bins + 1) u64]  zeroed per sweep, folded into the caller's arrays
 //   [chunk partial sums: slots x RT_NSUM doubles]                 every slot is written by the wave that walks its chunk
+//   [chunk depth bins: slots x 2 n_depth_bins doubles]            likewise
 struct WorkLayout {
-    size_t prefix_off, upload_bytes, next_off, tally_off, tally_words, sums_off, total;
+    size_t prefix_off, upload_bytes, next_off, tally_off, tally_words, sums_off, depth_off, total;
     uint32_t n_copies;
 };
 
@@ -264,7 +286,7 @@ uint32_t tally_copies(size_t words_per_copy) {
     return (uint32_t)(fit < 1 ? 1 : (fit > 64 ? 64 : fit));
 }
 
-WorkLayout work_layout(size_t n_atm, size_t slots, size_t tally_words_per_copy = 0) {
+WorkLayout work_layout(size_t n_atm, size_t slots, size_t tally_words_per_copy = 0, size_t n_depth = 0) {
     WorkLayout w;
     w.prefix_off = sizeof(rt::PlanEntry) * n_atm;
     w.upload_bytes = w.prefix_off + sizeof(uint32_t) * (n_atm + 1);
@@ -273,9 +295,13 @@ WorkLayout work_layout(size_t n_atm, size_t slots, size_t tally_words_per_copy =
     w.n_copies = tally_copies(tally_words_per_copy);
     w.tally_words = tally_words_per_copy * w.n_copies;
     w.sums_off = (w.tally_off + 8 * w.tally_words + 255) & ~(size_t)255;
-    w.total = w.sums_off + sizeof(double) * slots * RT_NSUM;
+    w.depth_off = (w.sums_off + sizeof(double) * slots * RT_NSUM + 255) & ~(size_t)255;
+    w.total = w.depth_off + sizeof(double) * slots * 2 * n_depth;
     return w;
 }
+
+// Largest work memory a sweep may ask for (the chunk depth bins dominate: 16 n_depth_bins bytes per chunk).
+constexpr size_t kMaxWorkBytes = (size_t)64 << 30;
 
 // The sweep behind rt_run_device (work memory from the context's growable buffer, kernel timed with events) and
 // rt_run_device_static (work memory = the static device array, nothing allocated, no timing).  Everything that can
@@ -291,7 +317,7 @@ int enqueue_sweep(rt_ctx* ctx, const rt_params* p, void* d_slab_sums, void* d_co
             if (p->table_of_atm[a] < 0 || p->table_of_atm[a] >= ctx->n_tables)
                 return fail(RT_ERR_INVALID, "atmosphere %d asks for table %d of %d", a, p->table_of_atm[a], ctx->n_tables);
     if (!d_slab_sums || !d_counts || !d_mu_hist) return fail(RT_ERR_INVALID, "device result buffer is NULL");
-    if (p->n_depth_bins > 0 && !d_depth) return fail(RT_ERR_INVALID, "d_depth is NULL but n_depth_bins > 0");
+    if (p->n_depth_bins > 0 && !d_depth) return fail(RT_ERR_INVALID, "d_slab_depth is NULL but n_depth_bins > 0");
     const int n_slabs = p->n_slabs > 0 ? p->n_slabs : 8;
     const int world = p->world > 0 ? p->world : 1;
     if (p->rank < 0 || p->rank >= world) return fail(RT_ERR_INVALID, "rank %d not in [0,%d)", p->rank, world);
@@ -303,18 +329,8 @@ int enqueue_sweep(rt_ctx* ctx, const rt_params* p, void* d_slab_sums, void* d_co
 
     rt::Cfg cfg = make_cfg(ctx, p);
     if (p->monochromatic_wl != 0.0) {
-        // CreatePhotons rounds the wavelength to 4 decimals and joins on exact equality (MC code.py:394,403-404).
-        const double want = std::round(p->monochromatic_wl * 1e4) / 1e4;
-        for (int i = 0; i < ctx->n_wl; ++i)
-            if (ctx->wl[i] == want || ctx->wl[i] == p->monochromatic_wl) {
-                cfg.mono_index = i;
-                break;
-            }
-        if (cfg.mono_index < 0)
-            return fail(RT_ERR_INVALID,
-                        "monochromatic wavelength %.6g has no exact match in the table (the reference would loop "
-                        "forever on NaN constants)",
-                        p->monochromatic_wl);
+        rc = find_monochromatic(ctx, p->monochromatic_wl, &cfg.mono_index);
+        if (rc) return rc;
     }
 
     // ---- plan: heaviest atmospheres first, chunked per slab ----
@@ -373,7 +389,10 @@ int enqueue_sweep(rt_ctx* ctx, const rt_params* p, void* d_slab_sums, void* d_co
     }
     prefix[p->n_atm] = (uint32_t)items;
     const size_t nmu = (size_t)p->n_mu_bins + 1;
-    const WorkLayout lay = work_layout(na, (size_t)items, na * (RT_NCNT + nmu));
+    const WorkLayout lay = work_layout(na, (size_t)items, na * (RT_NCNT + nmu), (size_t)p->n_depth_bins);
+    if (lay.total > kMaxWorkBytes)
+        return fail(RT_ERR_LIMIT, "this sweep needs %zu bytes of work memory (%llu chunks x %d depth bins); the limit is %zu: "
+                    "fewer depth bins or fewer photons per call", lay.total, items, p->n_depth_bins, kMaxWorkBytes);
 
     unsigned char* work = nullptr;
     if (use_static) {
@@ -388,6 +407,7 @@ int enqueue_sweep(rt_ctx* ctx, const rt_params* p, void* d_slab_sums, void* d_co
     }
     unsigned int* d_next = reinterpret_cast<unsigned int*>(work + lay.next_off);
     double* d_chunk_sums = reinterpret_cast<double*>(work + lay.sums_off);
+    double* d_chunk_depth = reinterpret_cast<double*>(work + lay.depth_off);
     unsigned long long* d_tally = reinterpret_cast<unsigned long long*>(work + lay.tally_off);
     unsigned long long* d_count_copies = d_tally;                                           // [n_copies][n_atm][RT_NCNT]
     unsigned long long* d_hist_copies = d_tally + (size_t)lay.n_copies * na * RT_NCNT;     // [n_copies][n_atm][nmu]
@@ -406,12 +426,12 @@ int enqueue_sweep(rt_ctx* ctx, const rt_params* p, void* d_slab_sums, void* d_co
     sw.owned_slabs = owned;
     sw.n_copies = lay.n_copies;
 
-    const rt::WalkVariant variant = pick_variant(p, cfg);
-    const size_t lds = rt::walk_lds_bytes(cfg.n_mu_bins, rt::walk_variant_has_depth(variant) ? cfg.n_depth_bins : 0);  // within the limit: check_common
-    int& cached = ctx->blocks_per_cu[variant];
-    if (cached <= 0 || ctx->blocks_lds[variant] != lds) {
+    const int variant = pick_variant(p, cfg);
+    const size_t lds = rt::walk_lds_bytes(cfg.n_mu_bins, rt::walk_variant(variant).has_depth ? cfg.n_depth_bins : 0);  // within the limit: check_common
+    int& cached = ctx->blocks_per_cu[(size_t)variant];  // asked once per variant and histogram size (no allocation)
+    if (cached <= 0 || ctx->blocks_lds[(size_t)variant] != lds) {
         cached = rt::walk_max_blocks_per_cu(variant, lds);
-        ctx->blocks_lds[variant] = lds;
+        ctx->blocks_lds[(size_t)variant] = lds;
     }
     ctx->last_variant = variant;
     const int per_cu = cached;
@@ -464,17 +484,18 @@ int enqueue_sweep(rt_ctx* ctx, const rt_params* p, void* d_slab_sums, void* d_co
     RT_HIP(hipMemcpyAsync(work, ctx->h_stage, lay.upload_bytes, hipMemcpyHostToDevice, stream));
     RT_HIP(hipEventRecord(ctx->staged, stream));
     ctx->staged_pending = true;
-    RT_HIP(rt::launch_zero_results(d_next, d_tally, lay.tally_words, (double*)d_depth, 2 * na * (size_t)p->n_depth_bins, stream));
+    RT_HIP(rt::launch_zero_results(d_next, d_tally, lay.tally_words, stream));
     EventPair* ev = nullptr;
     if (!use_static) {  // timing events are created on demand, which allocates: the static path is not timed
         RT_HIP(next_events(ctx, &ev));
         RT_HIP(hipEventRecord(ev->a, stream));
     }
     RT_HIP(rt::launch_walk(cfg, sw, variant, (int)grid, stream, d_next, d_chunk_sums, d_count_copies,
-                           d_hist_copies, (double*)d_depth));
+                           d_hist_copies, d_chunk_depth));
     if (ev) RT_HIP(hipEventRecord(ev->b, stream));
     RT_HIP(rt::launch_finish(sw, d_chunk_sums, (double*)d_slab_sums, d_count_copies, (unsigned long long*)d_counts,
-                             na * RT_NCNT, d_hist_copies, (unsigned long long*)d_mu_hist, na * nmu, stream));
+                             na * RT_NCNT, d_hist_copies, (unsigned long long*)d_mu_hist, na * nmu, d_chunk_depth,
+                             (double*)d_depth, p->n_depth_bins, stream));
     return RT_OK;
 }
 
@@ -533,17 +554,19 @@ int rt_create(rt_ctx** out, int device_id) {
         ctx->order.resize(kStaticMaxAtm);
         ctx->mu_base.resize(kStaticMaxAtm);
         // Load the library's device code now (the runtime does that, and allocates for it, at the first launch from a
-        // code object): rt_run_device_static must find nothing left to set up.  The launch clears the queue counter
-        // of the static work array.
-        e = rt::launch_zero_results(reinterpret_cast<unsigned int*>(ctx->static_scratch), nullptr, 0, nullptr, 0, ctx->stream);
+        // code object): rt_run_device_static must find nothing left to set up.  The launch writes nothing.
+        e = rt::launch_zero_results(nullptr, nullptr, 0, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) {
             rt_destroy(ctx);
             return fail(RT_ERR_DEVICE, "first kernel launch: %s", hipGetErrorString(e));
         }
-        for (int v = 0; v < rt::kWalkVariants; ++v) {
-            ctx->blocks_lds[v] = rt::walk_lds_bytes(10, 0);  // the default histogram; other sizes are queried when they occur
-            ctx->blocks_per_cu[v] = rt::walk_max_blocks_per_cu((rt::WalkVariant)v, ctx->blocks_lds[v]);
+        // occupancy of every walk-kernel variant with the default histogram (other sizes are asked when they occur)
+        ctx->blocks_per_cu.assign((size_t)rt::walk_variant_count(), 0);
+        ctx->blocks_lds.assign((size_t)rt::walk_variant_count(), 0);
+        for (int v = 0; v < rt::walk_variant_count(); ++v) {
+            ctx->blocks_lds[(size_t)v] = rt::walk_lds_bytes(10, 0);  // the default histogram; other sizes are queried when they occur
+            ctx->blocks_per_cu[(size_t)v] = rt::walk_max_blocks_per_cu(v, ctx->blocks_lds[(size_t)v]);
         }
     }
     // logarithm table for the kernels' ln(): c_j = 1 + (j + 1/2)/128, inv_c = fl(1/c_j), l = -ln(inv_c)
@@ -689,7 +712,7 @@ int rt_run(rt_ctx* ctx, const rt_params* p, rt_tallies* out) {
     RT_HIP(ctx->d_slab_sums.reserve(na * n_slabs * RT_NSUM));
     RT_HIP(ctx->d_counts.reserve(na * RT_NCNT));
     RT_HIP(ctx->d_mu_hist.reserve(na * nmu));
-    if (nd) RT_HIP(ctx->d_depth.reserve(2 * na * nd));
+    if (nd) RT_HIP(ctx->d_depth.reserve(na * n_slabs * 2 * nd));
     rt_params run = *p;
     size_t n_mu = 0;
     if (p->escaped_mu) {  // the kernel writes a device array; the caller's host array is filled from it below
@@ -715,12 +738,10 @@ int rt_run(rt_ctx* ctx, const rt_params* p, rt_tallies* out) {
     if (out->mu_hist)
         RT_HIP(hipMemcpyAsync(out->mu_hist, ctx->d_mu_hist.p, sizeof(uint64_t) * na * nmu, hipMemcpyDeviceToHost,
                               ctx->stream));
-    if (nd && out->depth_momentum)
-        RT_HIP(hipMemcpyAsync(out->depth_momentum, ctx->d_depth.p, sizeof(double) * na * nd, hipMemcpyDeviceToHost,
+    std::vector<double> slab_depth(nd && (out->depth_momentum || out->depth_energy) ? na * n_slabs * 2 * nd : 0);
+    if (!slab_depth.empty())
+        RT_HIP(hipMemcpyAsync(slab_depth.data(), ctx->d_depth.p, sizeof(double) * slab_depth.size(), hipMemcpyDeviceToHost,
                               ctx->stream));
-    if (nd && out->depth_energy)
-        RT_HIP(hipMemcpyAsync(out->depth_energy, ctx->d_depth.p + na * nd, sizeof(double) * na * nd,
-                              hipMemcpyDeviceToHost, ctx->stream));
     RT_HIP(hipStreamSynchronize(ctx->stream));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(RT_ERR_DEVICE, "walk kernel failed: %s", hipGetErrorString(e));
@@ -731,6 +752,15 @@ int rt_run(rt_ctx* ctx, const rt_params* p, rt_tallies* out) {
                 double s = 0.0;
                 for (int sl = 0; sl < n_slabs; ++sl) s += slab[(a * n_slabs + sl) * RT_NSUM + k];
                 out->sums[a * RT_NSUM + k] = s;
+            }
+    }
+    if (!slab_depth.empty()) {  // the slab axis summed in index order, like the sums: the same bits on any number of GPUs
+        for (size_t a = 0; a < na; ++a)
+            for (size_t k = 0; k < 2 * nd; ++k) {
+                double s = 0.0;
+                for (int sl = 0; sl < n_slabs; ++sl) s += slab_depth[(a * n_slabs + sl) * 2 * nd + k];
+                double* dst = k < nd ? out->depth_momentum : out->depth_energy;
+                if (dst) dst[a * nd + (k < nd ? k : k - nd)] = s;
             }
     }
     return RT_OK;
@@ -919,6 +949,9 @@ struct ShellUpload {
 
 int check_shell_model(const rt_shell_model* m) {
     if (!m) return fail(RT_ERR_INVALID, "model is NULL");
+    if (m->struct_size != sizeof(rt_shell_model))
+        return fail(RT_ERR_INVALID, "rt_shell_model.struct_size is %u, but this library's rt_shell_model has %zu bytes (ABI %d)",
+                    m->struct_size, sizeof(rt_shell_model), RT_ABI_VERSION);
     if (m->n_tau < 2 || m->n_age < 1 || !m->mc_tau || !m->mc_age || !m->mc_val)
         return fail(RT_ERR_INVALID, "the curve needs at least 2 optical depths and 1 age");
     for (int i = 1; i < m->n_tau; ++i)
@@ -1151,26 +1184,38 @@ struct Rccl {
 
 // librccl.so.1 is opened on first use, so that a process that never uses the collective does not load RCCL, and a
 // process that already has an RCCL of that name loaded (PyTorch ships one) shares it instead of loading a second.
-const Rccl* rccl() {
-    static Rccl r;
-    static bool tried = false;
-    if (!tried) {
-        tried = true;
+struct RcclLoad {
+    Rccl lib;
+    std::string error;  // why the library is not usable (kept: dlerror() reports a failure only once)
+    RcclLoad() {
         for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            r.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-            if (r.handle) break;
+            lib.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (lib.handle) break;
+            const char* msg = dlerror();
+            error = msg ? msg : "dlopen failed";
         }
-        if (r.handle) {
-            r.get_unique_id = reinterpret_cast<decltype(r.get_unique_id)>(dlsym(r.handle, "ncclGetUniqueId"));
-            r.comm_init_rank = reinterpret_cast<decltype(r.comm_init_rank)>(dlsym(r.handle, "ncclCommInitRank"));
-            r.comm_destroy = reinterpret_cast<decltype(r.comm_destroy)>(dlsym(r.handle, "ncclCommDestroy"));
-            r.all_reduce = reinterpret_cast<decltype(r.all_reduce)>(dlsym(r.handle, "ncclAllReduce"));
-            r.error_string = reinterpret_cast<decltype(r.error_string)>(dlsym(r.handle, "ncclGetErrorString"));
-            if (!r.get_unique_id || !r.comm_init_rank || !r.comm_destroy || !r.all_reduce || !r.error_string) r.handle = nullptr;
+        if (!lib.handle) return;
+        lib.get_unique_id = reinterpret_cast<decltype(lib.get_unique_id)>(dlsym(lib.handle, "ncclGetUniqueId"));
+        lib.comm_init_rank = reinterpret_cast<decltype(lib.comm_init_rank)>(dlsym(lib.handle, "ncclCommInitRank"));
+        lib.comm_destroy = reinterpret_cast<decltype(lib.comm_destroy)>(dlsym(lib.handle, "ncclCommDestroy"));
+        lib.all_reduce = reinterpret_cast<decltype(lib.all_reduce)>(dlsym(lib.handle, "ncclAllReduce"));
+        lib.error_string = reinterpret_cast<decltype(lib.error_string)>(dlsym(lib.handle, "ncclGetErrorString"));
+        if (!lib.get_unique_id || !lib.comm_init_rank || !lib.comm_destroy || !lib.all_reduce || !lib.error_string) {
+            error = "the RCCL library that was opened lacks an entry point (ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / "
+                    "ncclAllReduce / ncclGetErrorString)";
+            dlclose(lib.handle);
+            lib.handle = nullptr;
         }
     }
-    return r.handle ? &r : nullptr;
+};
+
+// Opened once, by whichever thread asks first (a function-local static: initialised exactly once, thread-safe).
+const RcclLoad* rccl_load() {
+    static const RcclLoad load;
+    return &load;
 }
+
+const Rccl* rccl() { return rccl_load()->lib.handle ? &rccl_load()->lib : nullptr; }
 
 #define RT_RCCL(lib, call)                                                                          \
     do {                                                                                            \
@@ -1185,7 +1230,7 @@ static_assert(sizeof(ncclUniqueId) == RT_COMM_ID_BYTES, "rt_comm_unique_id hands
 int rt_comm_unique_id(void* id) {
     if (!id) return fail(RT_ERR_INVALID, "id is NULL");
     const Rccl* lib = rccl();
-    if (!lib) return fail(RT_ERR_DEVICE, "librccl.so.1 could not be opened: %s", dlerror());
+    if (!lib) return fail(RT_ERR_DEVICE, "RCCL is not usable: %s", rccl_load()->error.c_str());
     ncclUniqueId u;
     RT_RCCL(lib, lib->get_unique_id(&u));
     memcpy(id, &u, sizeof u);
@@ -1197,7 +1242,7 @@ int rt_comm_init(rt_ctx* ctx, int rank, int world, const void* id) {
     if (world < 1 || rank < 0 || rank >= world) return fail(RT_ERR_INVALID, "rank %d not in [0,%d)", rank, world);
     if (ctx->comm) return fail(RT_ERR_STATE, "the context already has a communicator");
     const Rccl* lib = rccl();
-    if (!lib) return fail(RT_ERR_DEVICE, "librccl.so.1 could not be opened: %s", dlerror());
+    if (!lib) return fail(RT_ERR_DEVICE, "RCCL is not usable: %s", rccl_load()->error.c_str());
     RT_HIP(hipSetDevice(ctx->device));
     ncclUniqueId u;
     memcpy(&u, id, sizeof u);
@@ -1220,34 +1265,71 @@ int rt_comm_destroy(rt_ctx* ctx) {
     return RT_OK;
 }
 
-int rt_run_allreduce(rt_ctx* ctx, const rt_params* p, void* d_tallies, void* d_depth, void* stream_v) {
+int rt_run_allreduce(rt_ctx* ctx, const rt_params* p, void* d_tallies, void* stream_v) {
     if (!ctx) return fail(RT_ERR_INVALID, "ctx is NULL");
-    if (!p) return fail(RT_ERR_INVALID, "params is NULL");
     if (!ctx->comm) return fail(RT_ERR_STATE, "rt_comm_init must be called before rt_run_allreduce");
     if (!d_tallies) return fail(RT_ERR_INVALID, "d_tallies is NULL");
-    if (p->n_atm < 1) return fail(RT_ERR_INVALID, "n_atm must be >= 1 (got %d)", p->n_atm);
+    int rc = check_common(p);  // before p's sizes are used
+    if (rc) return rc;
     const int n_slabs = p->n_slabs > 0 ? p->n_slabs : 8;
-    const size_t na = (size_t)p->n_atm, nmu = (size_t)(p->n_mu_bins > 0 ? p->n_mu_bins : 0) + 1;
-    const size_t n_slab = na * n_slabs * RT_NSUM, n_cnt = na * RT_NCNT, n_hist = na * nmu;
+    const size_t na = (size_t)p->n_atm, nmu = (size_t)p->n_mu_bins + 1, nd = (size_t)p->n_depth_bins;
+    const size_t n_slab = na * n_slabs * RT_NSUM, n_cnt = na * RT_NCNT, n_hist = na * nmu, n_depth = na * n_slabs * 2 * nd;
     unsigned long long* words = static_cast<unsigned long long*>(d_tallies);
     rt_params run = *p;  // the communicator says which slabs this process walks
     run.rank = ctx->comm_rank;
     run.world = ctx->comm_world;
-    const int rc = enqueue_sweep(ctx, &run, words, words + n_slab, words + n_slab + n_cnt, d_depth, stream_v, false);
+    // A failure here is this process's alone (a refused argument, an allocation, a launch): the peers are then already
+    // waiting in ncclAllReduce, so the caller must tear the job down (see include/rt_amd.h).
+    rc = enqueue_sweep(ctx, &run, words, words + n_slab, words + n_slab + n_cnt, nd ? words + n_slab + n_cnt + n_hist : nullptr,
+                       stream_v, false);
     if (rc) return rc;
     const Rccl* lib = rccl();
     hipStream_t stream = (hipStream_t)stream_v;
-    // One collective: every slab-sum word is non-zero on exactly one rank and all-zero bits on the others, so the
-    // integer sum of the bit patterns returns that rank's double unchanged; counts and histogram add as integers.
-    RT_RCCL(lib, lib->all_reduce(words, words, n_slab + n_cnt + n_hist, ncclInt64, ncclSum, ctx->comm, stream));
-    if (p->n_depth_bins > 0)  // accumulated with floating-point atomics on every rank: a floating-point sum of its own
-        RT_RCCL(lib, lib->all_reduce(d_depth, d_depth, 2 * na * (size_t)p->n_depth_bins, ncclDouble, ncclSum, ctx->comm, stream));
+    // One collective: every slab word (sums and depth bins) is non-zero on exactly one rank and all-zero bits on the
+    // others, so the integer sum of the bit patterns returns that rank's double unchanged; counts and histogram add
+    // as integers.
+    RT_RCCL(lib, lib->all_reduce(words, words, n_slab + n_cnt + n_hist + n_depth, ncclInt64, ncclSum, ctx->comm, stream));
+    return RT_OK;
+}
+
+// The wavelength index (into the table's wl[]) and the starting cosine the sweeps give photon ids
+// [first_id, first_id + n) of atmosphere `atm` under p's seed, id base, stream and tables.
+int rt_emission_indices(rt_ctx* ctx, const rt_params* p, int32_t atm, uint64_t first_id, int64_t n, int32_t* out_index,
+                        double* out_mu0) {
+    if (!ctx) return fail(RT_ERR_INVALID, "ctx is NULL");
+    int rc = check_common(p);
+    if (rc) return rc;
+    if (ctx->n_wl < 1) return fail(RT_ERR_STATE, "rt_set_tables must be called before rt_emission_indices");
+    if (atm < 0 || atm >= p->n_atm) return fail(RT_ERR_INVALID, "atmosphere %d not in [0,%d)", atm, p->n_atm);
+    if (n < 0 || (n > 0 && !out_index)) return fail(RT_ERR_INVALID, "bad output array");
+    if (n > (1ll << 31)) return fail(RT_ERR_LIMIT, "at most 2^31 photon ids per call");
+    if (n == 0) return RT_OK;
+    const int table = p->table_of_atm ? p->table_of_atm[atm] : 0;
+    if (table < 0 || table >= ctx->n_tables) return fail(RT_ERR_INVALID, "atmosphere %d asks for table %d of %d", atm, table, ctx->n_tables);
+    RT_HIP(hipSetDevice(ctx->device));
+    rt::Cfg cfg = make_cfg(ctx, p);
+    cfg.table_base = table * ctx->n_wl;
+    if (p->monochromatic_wl != 0.0) {
+        rc = find_monochromatic(ctx, p->monochromatic_wl, &cfg.mono_index);
+        if (rc) return rc;
+    }
+    DevBuf<int32_t> d_idx;
+    DevBuf<double> d_mu;
+    hipError_t e = d_idx.reserve((size_t)n);
+    if (e == hipSuccess && out_mu0) e = d_mu.reserve((size_t)n);
+    if (e == hipSuccess) e = rt::launch_emission(cfg, p->rng_mode, (uint32_t)atm, first_id, (long long)n, d_idx.p, out_mu0 ? d_mu.p : nullptr, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out_index, d_idx.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && out_mu0) e = hipMemcpyAsync(out_mu0, d_mu.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    d_idx.release();
+    d_mu.release();
+    if (e != hipSuccess) return fail(RT_ERR_DEVICE, "emission kernel failed: %s", hipGetErrorString(e));
     return RT_OK;
 }
 
 const char* rt_last_kernel(rt_ctx* ctx) {
     if (!ctx || ctx->last_variant < 0) return "";
-    return rt::walk_variant_name((rt::WalkVariant)ctx->last_variant);
+    return rt::walk_variant(ctx->last_variant).name;
 }
 
 int rt_kernel_time(rt_ctx* ctx, double* avg_ms, int64_t* launches, int reset) {

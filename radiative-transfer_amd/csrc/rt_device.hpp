@@ -119,31 +119,44 @@ struct Cfg {
     int32_t quorum, pad2_;           // lean kernels: scattering lanes wait until this many have gathered (see walk_kernel)
 };
 
-// Which run flags a kernel has fixed at compile time.  Fixed<...>: loop order, lower boundary, scattering law and the
-// depth tally are template constants (abs_only off, slab geometry), so the code of every other option is not in
-// the kernel at all; Runtime: everything is read from cfg.
-template <int ORDER, int BOUNDARY, int LAW, bool DEPTH>
+// Which run flags a kernel has fixed at compile time.  Fixed<...>: loop order, lower boundary, scattering law, the
+// depth tally, abs_only, the geometry and the per-photon escape-cosine output are template constants, so the code of
+// every other option is not in the kernel at all; Runtime: everything is read from cfg.
+struct WalkKey {  // the same flags as data: what a sweep asks for, and what an instantiation serves
+    int32_t order, boundary, law;
+    bool depth, abs_only, shell, emu;
+    int32_t rng;  // RT_RNG_*
+    bool plain;   // rand_mu and monochromatic off as well (the reference's defaults)
+};
+
+template <int ORDER, int BOUNDARY, int LAW, bool DEPTH, bool ABS_ONLY = false, bool SHELL = false, bool EMU = false>
 struct Fixed {
     static constexpr bool kFixed = true;
     static constexpr bool kDepth = DEPTH;
     static constexpr bool kReemit = BOUNDARY == RT_BOUNDARY_REEMIT;
+    static constexpr bool kRejection = LAW == RT_SCATTER_DRAINE || LAW == RT_SCATTER_DRAINE_EXACT;
     static __device__ __forceinline__ bool gray(const Cfg&) { return ORDER == RT_ORDER_GRAY; }
     static __device__ __forceinline__ int boundary(const Cfg&) { return BOUNDARY; }
     static __device__ __forceinline__ int law(const Cfg&) { return LAW; }
     static __device__ __forceinline__ bool depth(const Cfg&) { return DEPTH; }
-    static __device__ __forceinline__ bool abs_only(const Cfg&) { return false; }
-    static __device__ __forceinline__ bool shell(const Cfg&) { return false; }
+    static __device__ __forceinline__ bool abs_only(const Cfg&) { return ABS_ONLY; }
+    static __device__ __forceinline__ bool shell(const Cfg&) { return SHELL; }
+    static __device__ __forceinline__ bool emu(const Cfg&) { return EMU; }
+    static WalkKey key() { return {ORDER, BOUNDARY, LAW, DEPTH, ABS_ONLY, SHELL, EMU, 0, false}; }
 };
 struct Runtime {
     static constexpr bool kFixed = false;
     static constexpr bool kDepth = true;
     static constexpr bool kReemit = true;
+    static constexpr bool kRejection = true;
     static __device__ __forceinline__ bool gray(const Cfg& c) { return c.order == RT_ORDER_GRAY; }
     static __device__ __forceinline__ int boundary(const Cfg& c) { return c.boundary; }
     static __device__ __forceinline__ int law(const Cfg& c) { return c.scatter; }
     static __device__ __forceinline__ bool depth(const Cfg& c) { return c.n_depth_bins > 0; }
     static __device__ __forceinline__ bool abs_only(const Cfg& c) { return c.abs_only != 0; }
     static __device__ __forceinline__ bool shell(const Cfg& c) { return c.geometry == RT_GEOM_SHELL; }
+    static __device__ __forceinline__ bool emu(const Cfg& c) { return c.escaped_mu != nullptr; }
+    static WalkKey key() { return {-1, -1, -1, true, true, true, true, 0, false}; }
 };
 // the reference's production configuration (MC code.py: reflecting floor, Henyey-Greenstein, two escape tests)
 typedef Fixed<RT_ORDER_MC, RT_BOUNDARY_REFLECT, RT_SCATTER_HG, false> FixedBase;
@@ -318,12 +331,23 @@ __device__ __forceinline__ void set_constants(const Cfg& cfg, double tau, const 
     ph.mu = mu0;
 }
 
+// BUF: alias entry and record through raw buffer loads (32-bit offsets), as the lean kernels' own emission.
+template <class V = Runtime, bool BUF = false>
 __device__ __forceinline__ void emit_from_table(const Cfg& cfg, double tau, PhiloxSrc& src, Photon& ph) {
     double ua, ub;
     src.emit_pair(ua, ub);
-    const int i = sample_index(cfg, ua);
-    const TableRec r = load_record(cfg, i);
-    set_constants<Runtime>(cfg, tau, r, i - cfg.table_base, cfg.rand_mu ? ub : 1.0, ph);
+    int i;
+    if (BUF && cfg.mono_index < 0) {  // sample_index() with the entry gathered by offset
+        const double x = ua * (double)cfg.n_wl;
+        int b = (int)x;
+        b = b < cfg.n_wl ? b : cfg.n_wl - 1;
+        const uint4 raw = gather16(cfg.alias, (uint32_t)(cfg.table_base + b) * 16u);
+        i = cfg.table_base + ((x - (double)b) < __hiloint2double((int)raw.y, (int)raw.x) ? b : (int)raw.z);
+    } else {
+        i = sample_index(cfg, ua);
+    }
+    const TableRec r = BUF ? load_record_buffer(cfg, i) : load_record(cfg, i);
+    set_constants<V>(cfg, tau, r, i - cfg.table_base, cfg.rand_mu ? ub : 1.0, ph);
 }
 
 // LEAN: the quotient by the unscaled division sequence (the IEEE quotient for the normal operands that occur: 0 <= z <= zmax)
@@ -526,7 +550,8 @@ __device__ __forceinline__ int scatter(const Cfg& cfg, Photon& ph, Src& src, dou
                 accept = draine_pdf(ph.g, cfg.alpha, cand) > y;  // uniform candidate, the reference's test
             } else {
                 if (ph.g != 0.0) {  // Henyey-Greenstein candidate (MC code.py:439); g = 0 is its isotropic limit
-                    const double q = ph.omg2 / (1.0 + ph.g * cand);
+                    // (FAST: the unscaled division, bit for bit the IEEE quotient on this domain, as in the HG branch)
+                    const double q = FAST ? div_unit(ph.omg2, 1.0 + ph.g * cand) : ph.omg2 / (1.0 + ph.g * cand);
                     cand = ph.inv2g * (ph.opg2 - q * q);
                 }
                 accept = 1.0 + cfg.alpha * cand * cand > y * (1.0 + cfg.alpha);

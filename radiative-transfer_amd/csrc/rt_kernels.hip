@@ -1,31 +1,20 @@
-// rt_kernels.hip -- gfx950 kernels of the photon random walk and their launchers.
+// rt_kernels.hip -- gfx950 kernels around the photon random walk and the launchers of all of them.
 //
-//   walk_kernel<FAST, PACKED, PLAIN>
-//                       persistent scatter kernel (FAST: the production configuration fixed at compile
-//                       time; otherwise every flag read at run time).  Every wave pulls work items
-//                       (atmosphere, chunk of photon ids) from a global queue; inside a
-//                       chunk each lane carries one photon in registers and dead lanes are
-//                       refilled from the chunk with a ballot / prefix count.  A chunk is
-//                       walked by exactly one wave and its lanes are reduced in a fixed
-//                       butterfly, so a chunk's partial sums depend only on the photon
-//                       ids in it, not on which wave, CU or GPU ran it.
-//   slab_reduce_kernel  sums the chunk partials of a slab in chunk order.
+//   zero_results_kernel / finish_kernel   before and after the walk: zero the tally copies; add the chunk partials of
+//                       every slab in a fixed shape, fold the tally copies.
 //   replay_kernel       one photon per thread on caller-supplied uniforms.
-//
-// Replaces RunPhotons (MC code.py:620-779, Numpy_random_walk.py:280-408) and the
-// atmosphere loop of runMC (MC code.py:1056-1062).
+//   emission_kernel     the wavelength index each photon id is emitted with.
+//   grain_integrals_kernel, selftest_math_kernel
+// The persistent walk kernel itself is a template (rt_walk.hpp) instantiated in rt_walk_*.hip; this file collects
+// the instantiations into one table.
 #include <algorithm>
-#include <type_traits>
+#include <mutex>
 
-#include "rt_kernels.hpp"
+#include "rt_walk.hpp"
 
 namespace rt {
 
-constexpr int kWavesPerBlock = kWalkBlock / 64;
-
 #ifdef RT_ABLATION
-// Experiment builds only (tools/wave_trace.py): per wave of the last walk launch, 100 MHz clock at its first queue pop,
-// at the start of its last chunk and at its end, and the number of chunks it walked.
 __device__ unsigned long long g_wave_trace[8 * 8192];
 extern "C" int rt_debug_wave_trace(unsigned long long* out, int n_waves) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_trace), sizeof(unsigned long long) * 8 * (size_t)n_waves);
@@ -34,442 +23,12 @@ extern "C" int rt_debug_wave_trace(unsigned long long* out, int n_waves) {
 __device__ unsigned long long g_wave_trace[1];  // never written: Ablation::kWaveTrace is false
 #endif
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
-
-__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
-
-constexpr size_t kLogTableBytes = sizeof(LogTableEntry) * kLogTableEntries;
-constexpr size_t kCoefBytes = sizeof(double) * 16;  // kMathCoefs polynomial coefficients, padded
-constexpr size_t kMathLdsBytes = kLogTableBytes + kCoefBytes;
-static_assert(kMathCoefs <= 16, "coefficient block");
-
-// LDS layout per block: the logarithm table (2 KiB) and the polynomial coefficients of ln / cos (128 B), then
-// [waves][2*nd] doubles (depth momentum, depth energy), then [waves][nmu] u32 (escape-cosine histogram).
-// The histograms are private to a wave; table and coefficients are shared and read-only after
-// stage_log_table().  The production kernel reads the coefficients from LDS where it uses them: held in
-// registers across the loop they took 28 of its 115 vector registers, without them it fits 5 waves per SIMD
-// instead of 4.
-__device__ __forceinline__ Hist wave_hist(unsigned char* lds_raw, int wave, int nmu, int nd) {
-    double* depth_base = reinterpret_cast<double*>(lds_raw + kMathLdsBytes) + (size_t)wave * 2 * nd;
-    uint32_t* mu_base =
-        reinterpret_cast<uint32_t*>(lds_raw + kMathLdsBytes + sizeof(double) * (size_t)kWavesPerBlock * 2 * nd) +
-        (size_t)wave * nmu;
-    Hist h;
-    h.mu = mu_base;
-    h.depth_mom = nd ? depth_base : nullptr;
-    h.depth_en = nd ? depth_base + nd : nullptr;
-    h.log_table = reinterpret_cast<const LogTableEntry*>(lds_raw);
-    h.coef = reinterpret_cast<const double*>(lds_raw + kLogTableBytes);
-    return h;
-}
-
-// Every thread of the block calls this once, before any divergence.
-__device__ __forceinline__ void stage_log_table(const Cfg& cfg, unsigned char* lds_raw) {
-    LogTableEntry* dst = reinterpret_cast<LogTableEntry*>(lds_raw);
-    for (int k = threadIdx.x; k < kLogTableEntries; k += blockDim.x) dst[k] = cfg.log_table[k];
-    if (threadIdx.x < kMathCoefs) reinterpret_cast<double*>(lds_raw + kLogTableBytes)[threadIdx.x] = math_coef((int)threadIdx.x);
-    __syncthreads();
-}
-
-__device__ __forceinline__ void clear_hist(const Hist& h, int lane, int nmu, int nd) {
-    for (int k = lane; k < nmu; k += 64) h.mu[k] = 0u;
-    for (int k = lane; k < 2 * nd; k += 64) h.depth_mom[k] = 0.0;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-}
-
-// Moves the wave's LDS histograms into the global tallies of atmosphere `atm` and zeroes them.
-__device__ __forceinline__ void flush_hist(const Hist& h, int lane, int nmu, int nd, uint32_t atm, uint32_t n_atm,
-                                           unsigned long long* d_mu_hist, double* d_depth) {
-    __builtin_amdgcn_wave_barrier();
-    for (int k = lane; k < nmu; k += 64) {
-        const uint32_t v = atomicExch(&h.mu[k], 0u);
-        if (v) atomicAdd(&d_mu_hist[(size_t)atm * nmu + k], (unsigned long long)v);
-    }
-    for (int k = lane; k < 2 * nd; k += 64) {
-        const unsigned long long bits = atomicExch(reinterpret_cast<unsigned long long*>(&h.depth_mom[k]), 0ull);
-        const double v = __longlong_as_double((long long)bits);
-        const int which = k >= nd;  // 0: momentum, 1: energy
-        if (v != 0.0) atomicAdd(&d_depth[((size_t)which * n_atm + atm) * nd + (k - which * nd)], v);
-    }
-    __builtin_amdgcn_wave_barrier();
-}
-
-// A wave-uniform value moved to scalar registers, so that what is computed from it runs on the scalar unit.
-__device__ __forceinline__ unsigned long long uniform64(unsigned long long v) {
-    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
-    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
-    return ((unsigned long long)hi << 32) | lo;
-}
-
-// One unit of work for a wave: a chunk of consecutive photon ids of one atmosphere.
-struct WorkItem {
-    unsigned long long cursor, end;  // photon ids [cursor, end) before id_base is added
-    double tau;
-    uint32_t atm;
-    uint32_t table;
-    size_t slot;  // where this chunk's partial sums go
-    unsigned long long mu_base;  // first entry of the atmosphere in Cfg::escaped_mu
-};
-
-// Pops the next item of the global queue (wave-uniform).  Returns false when the queue is empty.
-__device__ __forceinline__ bool pop_item(const Sweep& sw, unsigned int* d_next, int lane, WorkItem& it) {
-    unsigned int q = 0;
-    if (lane == 0) q = atomicAdd(d_next, 1u);
-    q = __builtin_amdgcn_readfirstlane(q);
-    if (q >= sw.n_items) return false;
-    if (sw.mix_groups) {
-        const uint32_t per = sw.mix_rh + sw.mix_rl, mixed = sw.mix_groups * per;
-        if (q < mixed) {
-            const uint32_t g = q / per, p = q - g * per;
-            q = p < sw.mix_rh ? g * sw.mix_rh + p : sw.mix_h + g * sw.mix_rl + (p - sw.mix_rh);
-        } else {
-            const uint32_t t = q - mixed, rem_h = sw.mix_h - sw.mix_groups * sw.mix_rh;
-            q = t < rem_h ? sw.mix_groups * sw.mix_rh + t : sw.mix_h + sw.mix_groups * sw.mix_rl + (t - rem_h);
-        }
-    } else if (q < sw.n_interleaved) {
-        q = (q & (kQueueRows - 1u)) * sw.row_len + (q >> kQueueRowsLog2);
-    }
-    // Sorted position lo with item_prefix[lo] <= q < item_prefix[lo+1], searched 64 ways at a time: every lane
-    // reads one entry of the candidate range, a ballot picks the sub-range -- two dependent loads for up to 4096
-    // atmospheres where a binary search has twelve (the wave idles through each of them once per chunk).
-    uint32_t lo = 0u, span = sw.n_atm;  // candidates lo .. lo + span - 1; item_prefix[lo] <= q holds throughout
-    while (span > 1u) {
-        const uint32_t step = (span + 63u) >> 6;
-        const uint32_t idx = lo + (uint32_t)lane * step;
-        const uint32_t v = idx < lo + span ? sw.item_prefix[idx] : 0xffffffffu;
-        const uint32_t below = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(v <= q));  // >= 1: lane 0 reads item_prefix[lo]
-        const uint32_t end = lo + span;
-        lo += (below - 1u) * step;
-        span = end - lo < step ? end - lo : step;
-    }
-    lo = __builtin_amdgcn_readfirstlane(lo);
-    const PlanEntry plan = sw.plan[lo];
-    const unsigned int local = q - sw.item_prefix[lo];
-    const unsigned int j = local / plan.chunks;  // ordinal among the slabs this rank owns
-    const unsigned int c = local - j * plan.chunks;
-    const unsigned long long slab = (unsigned long long)sw.rank + (unsigned long long)j * sw.world;
-    const unsigned long long slab_lo = slab * plan.slab_len;
-    unsigned long long slab_hi = slab_lo + plan.slab_len;
-    slab_hi = slab_hi < plan.n_photons ? slab_hi : plan.n_photons;
-    const unsigned long long first = slab_lo + (unsigned long long)c * plan.chunk;
-    const unsigned long long e = first + plan.chunk;
-    it.cursor = uniform64(first);
-    it.end = uniform64(e < slab_hi ? e : slab_hi);
-    it.tau = __longlong_as_double((long long)uniform64((unsigned long long)__double_as_longlong(plan.tau)));
-    it.atm = __builtin_amdgcn_readfirstlane(plan.atm);
-    it.table = __builtin_amdgcn_readfirstlane(plan.table);
-    it.slot = (size_t)uniform64((unsigned long long)plan.slot_base + (unsigned long long)j * plan.chunks + c);
-    it.mu_base = uniform64(plan.mu_base);
-    return true;
-}
-
-// Chunk epilogue: lanes reduced in a fixed butterfly, one partial per chunk; integer tallies
-// and histograms go to the global arrays with atomics (order-independent).
-__device__ __forceinline__ void store_chunk(const Acc& acc, const WorkItem& it, const Hist& hist, int lane, int nmu,
-                                            int nd, uint32_t n_atm, double* d_chunk_sums,
-                                            unsigned long long* d_counts, unsigned long long* d_mu_hist,
-                                            double* d_depth) {
-#pragma unroll
-    for (int k = 0; k < RT_NSUM; ++k) {
-        const double v = wave_sum(acc.s[k]);
-        if (lane == 0) d_chunk_sums[it.slot * RT_NSUM + k] = v;
-    }
-#pragma unroll
-    for (int k = 0; k < RT_NCNT; ++k) {
-        const uint32_t v = wave_sum_u32(acc.c[k]);
-        if (lane == 0 && v) atomicAdd(&d_counts[(size_t)it.atm * RT_NCNT + k], (unsigned long long)v);
-    }
-    flush_hist(hist, lane, nmu, nd, it.atm, n_atm, d_mu_hist, d_depth);
-}
-
-// Same for the fast kernel: the integer tallies are already wave totals (wave-uniform values).
-template <bool REEMITS>
-__device__ __forceinline__ void store_chunk_wave(const AccWave& acc, const unsigned long long (&wc)[RT_NCNT],
-                                                 const WorkItem& it, const Hist& hist, int lane, int nmu, int nd,
-                                                 uint32_t n_atm, double* d_chunk_sums, unsigned long long* d_counts,
-                                                 unsigned long long* d_mu_hist, double* d_depth) {
-#pragma unroll
-    for (int k = 0; k < RT_NSUM; ++k) {
-        const double v = wave_sum(acc.s[k]);
-        if (lane == 0) d_chunk_sums[it.slot * RT_NSUM + k] = v;
-    }
-    const uint32_t hits = wave_sum_u32(acc.hits);
-    const uint32_t reemits = REEMITS ? wave_sum_u32(acc.reemits) : 0u;
-#pragma unroll
-    for (int k = 0; k < RT_NCNT; ++k) {
-        const unsigned long long v = k == RT_CNT_BOUNDARY_HITS ? (unsigned long long)hits
-                                     : k == RT_CNT_REEMITTED   ? (unsigned long long)reemits
-                                                               : wc[k];
-        if (lane == 0 && v) atomicAdd(&d_counts[(size_t)it.atm * RT_NCNT + k], v);
-    }
-    flush_hist(hist, lane, nmu, nd, it.atm, n_atm, d_mu_hist, d_depth);
-}
-
-// The persistent walk kernel.  The loop is rotated so that the two lane populations that exist after a
-// flight -- lanes whose photon ended (they need a new photon) and lanes whose photon goes on to
-// scatter -- share ONE Philox call: each lane feeds its own counter (emission block of the new
-// photon id, or the scattering block of the current one) and the 128 output bits are then read
-// as the emission draws or as (azimuth, cosine).  The alias-table entry of the new photons is
-// requested before the scattering arithmetic runs, so the first gather's latency hides under it.
-//   V = Fixed<order, boundary, law, depth>  these flags fixed at compile time (abs_only off, slab geometry): the lean
-//                 loop with integer tallies per wave.  FixedBase is the reference's production configuration
-//                 (RT_ORDER_MC, reflecting boundary, Henyey-Greenstein, no depth bins).
-//   V = Runtime   every boundary / scattering law / loop order, depth bins, abs_only, shell geometry, read from cfg.
-// Both give the same photon histories as one fly() + scatter() per photon per iteration (flight()).
-//   PLAIN (with FAST) also fixes the reference's defaults rand_mu = 0 and monochromatic = 0 at compile time: the
-//                 selects they cost per emission, and the scalar registers their operands occupy, go away.
-template <class V, bool PACKED, bool PLAIN>
-__global__ __launch_bounds__(kWalkBlock) void walk_kernel(const Cfg cfg0, const Sweep sw,
-                                                           unsigned int* __restrict__ d_next,
-                                                           double* __restrict__ d_chunk_sums,
-                                                           unsigned long long* __restrict__ d_counts,
-                                                           unsigned long long* __restrict__ d_mu_hist,
-                                                           double* __restrict__ d_depth) {
-    // d_counts [n_copies][n_atm][RT_NCNT], d_mu_hist [n_copies][n_atm][n_mu_bins + 1]
-    extern __shared__ __align__(16) unsigned char lds_raw[];
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int nmu = cfg0.n_mu_bins + 1;
-    constexpr bool FAST = V::kFixed;  // lean loop: wave-level integer tallies, scalar lane bookkeeping, buffer loads
-    const int nd = V::kDepth ? cfg0.n_depth_bins : 0;
-    const Hist hist = wave_hist(lds_raw, wave, nmu, nd);
-    stage_log_table(cfg0, lds_raw);
-    clear_hist(hist, lane, nmu, nd);
-    // Integer tallies and the escape histogram go to one of n_copies copies of the tally arrays (folded afterwards):
-    // with one copy, all the waves that finish chunks of the same atmosphere queue up on the same few cache lines.
-    {
-        const uint32_t copy = __builtin_amdgcn_readfirstlane(((uint32_t)blockIdx.x * kWavesPerBlock + (uint32_t)wave) % sw.n_copies);
-        d_counts += (size_t)copy * sw.n_atm * RT_NCNT;
-        d_mu_hist += (size_t)copy * sw.n_atm * (size_t)nmu;
-    }
-
-    unsigned long long t_begin = 0ull, t_last = 0ull, n_done = 0ull;
-    unsigned long long n_iter = 0ull, n_drain = 0ull, n_drain_few = 0ull, n_lanes = 0ull;  // experiment builds only
-    if constexpr (Ablation::kWaveTrace) t_begin = t_last = wall_clock64();
-    WorkItem it;
-    while (pop_item(sw, d_next, lane, it)) {
-        if constexpr (Ablation::kWaveTrace) {
-            t_last = wall_clock64();
-            ++n_done;
-        }
-        const double tau = it.tau;
-        Cfg cfg = cfg0;  // this atmosphere's table (wave-uniform)
-        cfg.table_base = (int32_t)(it.table * (uint32_t)cfg0.n_wl);
-        typename std::conditional<FAST, AccWave, Acc>::type acc;
-        acc.clear();
-        // FAST: wave totals in scalar registers.  A chunk has at most 16384 photons, so everything that happens
-        // once per photon fits 32 bits; scatterings do not (up to max_events per photon).
-        uint32_t n_photons = 0u, n_escaped = 0u, n_uncounted = 0u, n_guarded = 0u, n_floor = 0u;
-        unsigned long long n_scatter = 0ull;
-        Photon ph = {};
-        PhiloxSrc src = {};
-        src.atm = it.atm;
-        src.k0 = cfg.k0;
-        src.k1 = cfg.k1;
-        bool alive = false;  // at the top of the loop a live lane is one that must scatter
-
-        // CheckBoundary 'reemit' (MC code.py:539-547): fresh table values and direction, same history
-        auto reemit = [&](Photon& p) {
-            if (V::boundary(cfg) == RT_BOUNDARY_REEMIT) {
-                const double p0 = p.p0, e1 = p.e1, b = p.b;
-                const uint32_t n_it = p.iter;
-                const int ns = p.n_scatter;
-                emit_from_table(cfg, tau, src, p);
-                p.p0 = p0;
-                p.e1 = e1;
-                p.b = b;
-                p.iter = n_it;
-                p.n_scatter = ns;
-            }
-        };
-
-        // FAST: the lanes without a photon as a wave-uniform mask, carried from one iteration to the next, so that
-        // every count the loop needs is scalar arithmetic on masks (a ballot of a lane predicate that lives in a
-        // mask register costs a select and a compare per use)
-        unsigned long long dead = ~0ull;
-        // position in the chunk as 32-bit scalars (a chunk has at most 16384 ids; the scalar unit compares 32 bits)
-        const unsigned long long id0 = it.cursor + cfg.id_base;
-        // (a queued chunk can lie wholly beyond the end of a short last slab: it.end < it.cursor, no photons)
-        const uint32_t len = it.end > it.cursor ? (uint32_t)(it.end - it.cursor) : 0u;
-        uint32_t cur = 0u;
-        for (;;) {
-            // ---- hand new photon ids to dead lanes (ballot + prefix count) ----
-            bool fresh = false;
-            if (!FAST) dead = __builtin_amdgcn_ballot_w64(!alive);
-            const uint32_t n_dead = (uint32_t)__popcll(dead);
-            uint32_t n_new = 0u;               // photons started in this iteration (wave-uniform)
-            unsigned long long idle = dead;  // FAST: the lanes without a photon that get none in this iteration
-            if (dead != 0ull && cur < len) {
-                const unsigned int my_off =
-                    __builtin_amdgcn_mbcnt_hi((uint32_t)(dead >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dead, 0u));
-                const uint32_t left = len - cur;
-                n_new = left < n_dead ? left : n_dead;
-                // the first n_new dead lanes, in lane order, take the chunk's next ids
-                const bool take = my_off < n_new;
-                // (the comparison's own lane mask: a ballot of `take` would go through a select and a second compare)
-                if (FAST) idle = dead & ~__builtin_amdgcn_uicmp(my_off, n_new, 36 /* unsigned < */);
-                if (!alive && take) {
-                    const unsigned long long gid = (id0 + cur) + my_off;  // scalar base + lane offset
-                    src.id_lo = (uint32_t)gid;
-                    src.id_hi = (uint32_t)(gid >> 32);
-                    src.blk = 0u;
-                    src.n_emit = 1u;  // the emission block of this iteration is number 0
-                    fresh = true;
-                }
-                cur += n_dead;  // may pass len: the chunk is used up then
-            }
-            // FAST: the lanes whose photon goes on to scatter wait (in place, masked out) until at least `quorum` of
-            // them have gathered, while the other lanes keep starting photons: in atmospheres where only a few per cent
-            // of the flights end in a scattering, the scattering code then runs once for many lanes instead of in almost
-            // every iteration for one or two.  With nothing left to start they always go.  The decision depends on the
-            // wave's own lane states only, so a chunk's results stay reproducible.
-            const bool go = !FAST || 64u - n_dead >= (uint32_t)cfg.quorum || n_new == 0u;
-            const bool active = (alive && go) || fresh;
-            // FAST: 64 - n_dead lanes hold a photon, n_new start one (a wave of this kernel has 64 lanes)
-            if (FAST ? n_dead - n_new == 64u : __builtin_amdgcn_ballot_w64(active) == 0ull) break;
-            if (FAST) {
-                n_photons += n_new;
-                n_scatter += go ? 64u - n_dead : 0u;
-            }
-            if constexpr (Ablation::kWaveTrace && FAST) {  // iterations, those after the chunk ran out, lanes at work
-                const uint32_t busy = n_new + (go ? 64u - n_dead : 0u);
-                ++n_iter;
-                n_lanes += busy;
-                if (cur >= len) {
-                    ++n_drain;
-                    if (busy <= 4u) ++n_drain_few;
-                }
-            }
-            int fate = 0;
-            if (active) {
-                // ---- one Philox call: emission block for fresh lanes, scattering block otherwise ----
-                // (PACKED: the photon's next block serves both, and the flight below as well)
-                const uint32_t block = PACKED ? src.blk : (fresh ? kEmitBlock : src.blk);
-                const PhiloxOut o = philox4x32_10(src.id_lo, src.id_hi, block, src.atm, src.k0, src.k1);
-                // the production kernel keeps its first draw as m = 1 + u (MFORM): both uses are exact affine forms
-                constexpr bool MFORM = FAST && !PACKED;
-                const double ua = MFORM ? m52(o.w0, o.w1) : ((!PACKED || fresh) ? u52(o.w0, o.w1) : u32mid(o.w0));
-                double ub = PACKED ? u32mid(o.w1) : u52(o.w2, o.w3);
-                // alias entry of the new photons' bucket, requested now; scattering lanes read entry 0 (broadcast)
-                const double xb = MFORM ? fma(ua, (double)cfg.n_wl, -(double)cfg.n_wl) : ua * (double)cfg.n_wl;
-                int bucket = (int)xb;
-                bucket = bucket < cfg.n_wl ? bucket : cfg.n_wl - 1;
-                bucket = fresh ? bucket : 0;
-                const uint4 raw = FAST ? gather16(cfg.alias, (uint32_t)(cfg.table_base + bucket) * 16u)
-                                       : *reinterpret_cast<const uint4*>(&cfg.alias[cfg.table_base + bucket]);
-                int scatter_fate = 0;
-                if (!fresh) {
-                    ++src.blk;
-                    scatter_fate = scatter<V, FAST, MFORM>(cfg, ph, src, ua, ub, 2, acc, hist);
-                }
-                const double prob = __hiloint2double((int)raw.y, (int)raw.x);
-                int idx = (xb - (double)bucket) < prob ? bucket : (int)raw.z;
-                if (!PLAIN) idx = cfg.mono_index >= 0 ? cfg.mono_index : idx;
-                const int local = fresh ? idx : 0;
-                idx = fresh ? cfg.table_base + idx : 0;
-                const TableRec rec = FAST ? load_record_buffer(cfg, idx) : load_record(cfg, idx);
-                // the iteration guard: ph.iter flights so far.  In the production kernel a photon that has flown k times
-                // has used 2k blocks at this point, so the block counter serves and ph.iter need not be kept.
-                const bool too_long = MFORM ? src.blk >= 2u * (uint32_t)cfg.max_events : ph.iter >= (uint32_t)cfg.max_events;
-                const bool guard = scatter_fate != 0 || (!fresh && too_long);
-                double u_step, u_abs;
-                if (PACKED) {
-                    if (fresh) ++src.blk;
-                    u_step = u32mid(o.w2);
-                    u_abs = u32mid(o.w3);
-                    if (!PLAIN && cfg.rand_mu && fresh) {  // the direction draw of a new photon: second uniform of emission block 0
-                        const PhiloxOut e = philox4x32_10(src.id_lo, src.id_hi, kEmitBlock, src.atm, src.k0, src.k1);
-                        ub = u52(e.w2, e.w3);
-                    }
-                } else {
-                    src.pair(u_step, u_abs);
-                }
-                if (fresh) {
-                    set_constants<V>(cfg, tau, rec, local, (!PLAIN && cfg.rand_mu) ? ub : 1.0, ph);
-                    start_photon(ph, acc);
-                    alive = true;
-                }
-                if (guard) {
-                    fate = RT_FATE_GUARD;
-                } else {
-                    int n_used = 0;
-                    // FAST: polynomial coefficients from LDS (5 waves per SIMD); the generic kernel is bound by its
-                    // other registers (3 waves per SIMD either way) and keeps them in registers
-                    const double path = FAST ? -log_unit(u_step, hist.log_table, hist.coef) : -log_unit(u_step, hist.log_table);
-                    fate = fly_path<V>(cfg, ph, path, u_abs, 2, false, acc, hist, reemit, n_used);
-                }
-                if (fate != 0) {
-                    if (!FAST && cfg.escaped_mu) {  // the reference's escaped_mu list, photon by photon
-                        const unsigned long long gid = ((unsigned long long)src.id_hi << 32) | src.id_lo;
-                        const bool logged = fate == RT_FATE_ESCAPED_UNCOUNTED ||
-                                            (fate == RT_FATE_ESCAPED && (V::gray(cfg) || V::shell(cfg)));
-                        cfg.escaped_mu[it.mu_base + (gid - cfg.id_base)] = logged ? ph.mu : __builtin_nan("");
-                    }
-                    retire<PLAIN, V>(cfg, ph, fate, acc, hist);
-                    alive = false;
-                }
-            }
-            if (FAST) {
-                n_guarded += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(fate == RT_FATE_GUARD));
-                n_escaped += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(fate == RT_FATE_ESCAPED));
-                n_uncounted += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(fate == RT_FATE_ESCAPED_UNCOUNTED));
-                if (V::boundary(cfg) == RT_BOUNDARY_ABSORB)
-                    n_floor += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(fate == RT_FATE_BOUNDARY));
-                // lanes without a photon at the top of the next iteration: those whose photon ended now (fate is 0
-                // in lanes that were not active) and the dead lanes that got no new one (only when the chunk runs out)
-                dead = __builtin_amdgcn_ballot_w64(fate != 0) | idle;
-            }
-        }
-        if constexpr (FAST) {
-            unsigned long long wc[RT_NCNT] = {};
-            wc[RT_CNT_PHOTONS] = n_photons;
-            wc[RT_CNT_SCATTER] = n_scatter;
-            wc[RT_CNT_ESCAPED] = n_escaped;
-            wc[RT_CNT_ESCAPED_UNCOUNTED] = n_uncounted;
-            wc[RT_CNT_GUARD] = n_guarded;
-            wc[RT_CNT_BOUNDARY_ABSORBED] = n_floor;
-            // one flight per photon started and per scattering, except where the iteration guard ended the photon
-            // after its scattering (fly_path itself never returns RT_FATE_GUARD for an unbounded stream)
-            wc[RT_CNT_FLIGHTS] = n_scatter + n_photons - n_guarded;
-            // every photon started in this chunk also ended in it
-            wc[RT_CNT_ABSORBED] = wc[RT_CNT_PHOTONS] - wc[RT_CNT_ESCAPED] - wc[RT_CNT_ESCAPED_UNCOUNTED] - wc[RT_CNT_GUARD] - n_floor;
-            store_chunk_wave<V::kReemit>(acc, wc, it, hist, lane, nmu, nd, sw.n_atm, d_chunk_sums, d_counts, d_mu_hist, d_depth);
-        } else {
-            store_chunk(acc, it, hist, lane, nmu, nd, sw.n_atm, d_chunk_sums, d_counts, d_mu_hist, d_depth);
-        }
-    }
-    if constexpr (Ablation::kWaveTrace) {
-        if (lane == 0) {
-            unsigned long long* t = g_wave_trace + 8 * (size_t)(blockIdx.x * kWavesPerBlock + wave);
-            t[0] = t_begin;
-            t[1] = t_last;  // start of this wave's last chunk
-            t[2] = wall_clock64();
-            t[3] = n_done;
-            t[4] = n_iter;
-            t[5] = n_drain;      // iterations after the chunk's last id was handed out
-            t[6] = n_drain_few;  // ... with at most 4 lanes at work
-            t[7] = n_lanes;      // lanes at work summed over the iterations
-        }
-    }
-}
-
-// Zeroes what a sweep accumulates into with atomics: the queue counter, the tally copies and the depth arrays.
-__global__ void zero_results_kernel(unsigned int* __restrict__ d_next, unsigned long long* __restrict__ a, size_t na,
-                                    unsigned long long* __restrict__ b, size_t nb) {
+// Zeroes what a sweep accumulates into with atomics: the queue counter and the tally copies.
+__global__ void zero_results_kernel(unsigned int* __restrict__ d_next, unsigned long long* __restrict__ a, size_t na) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t == 0) *d_next = 0u;
+    if (t == 0 && d_next) *d_next = 0u;
     for (size_t i = t; i < na; i += stride) a[i] = 0ull;
-    for (size_t i = t; i < nb; i += stride) b[i] = 0ull;
 }
 
 // What follows the walk, in one launch of 64-thread workgroups.
@@ -477,16 +36,37 @@ __global__ void zero_results_kernel(unsigned int* __restrict__ d_next, unsigned 
 //   owned slab's chunk partials are added in a fixed shape -- lane l takes the slots l, l + 64, ... in order, then the
 //   lanes are combined by the butterfly -- that depends on the slab's chunk count only.  Every slot of the range was
 //   written by the walk kernel (a chunk beyond the end of a short last slab holds zeros).
-//   The remaining workgroups fold the copies of the integer tallies (counts, then the escape histogram) into the
+//   The next workgroups fold the copies of the integer tallies (counts, then the escape histogram) into the
 //   caller's arrays: out[i] = sum over the copies of in[c * n + i] (integers: any order gives the same bits).
+//   The last n_atm * n_slabs * ceil(2 n_depth / 64) workgroups add the depth-resolved deposition of each slab: lane l
+//   owns entry l of a block of 64 of the slab's 2 n_depth entries and adds the chunks' values in chunk order.
 __global__ __launch_bounds__(64) void finish_kernel(const Sweep sw, const double* __restrict__ d_chunk_sums,
                                                     double* __restrict__ d_slab_sums,
                                                     const unsigned long long* __restrict__ d_count_copies,
                                                     unsigned long long* __restrict__ d_counts, uint32_t n_counts,
                                                     const unsigned long long* __restrict__ d_hist_copies,
-                                                    unsigned long long* __restrict__ d_mu_hist, uint32_t n_hist) {
+                                                    unsigned long long* __restrict__ d_mu_hist, uint32_t n_hist,
+                                                    const double* __restrict__ d_chunk_depth,
+                                                    double* __restrict__ d_slab_depth, uint32_t n_depth) {
     const int lane = threadIdx.x;
     const unsigned int n_reduce = sw.n_atm * sw.n_slabs;
+    const unsigned int n_fold = (n_counts + n_hist + 63u) / 64u;
+    if (blockIdx.x >= n_reduce + n_fold) {
+        const unsigned int per_slab = (2u * n_depth + 63u) / 64u;
+        const unsigned int b = blockIdx.x - n_reduce - n_fold;
+        const unsigned int as = b / per_slab, entry = (b - as * per_slab) * 64u + (unsigned int)lane;
+        if (entry >= 2u * n_depth) return;
+        const unsigned int a = as / sw.n_slabs, slab = as - a * sw.n_slabs;
+        const PlanEntry plan = sw.plan[a];
+        double s = 0.0;
+        if (slab % sw.world == sw.rank) {
+            const unsigned int j = slab / sw.world;
+            const double* src = d_chunk_depth + ((size_t)plan.slot_base + (size_t)j * plan.chunks) * (2u * n_depth) + entry;
+            for (unsigned int c = 0; c < plan.chunks; ++c) s += src[(size_t)c * (2u * n_depth)];
+        }
+        d_slab_depth[((size_t)plan.atm * sw.n_slabs + slab) * (2u * n_depth) + entry] = s;
+        return;
+    }
     if (blockIdx.x >= n_reduce) {
         const unsigned int i = (blockIdx.x - n_reduce) * 64u + (unsigned int)lane;
         const bool is_count = i < n_counts;
@@ -519,6 +99,24 @@ __global__ __launch_bounds__(64) void finish_kernel(const Sweep sw, const double
     for (int k = 0; k < RT_NSUM; ++k) {
         const double v = wave_sum(s[k]);
         if (lane == 0) d_slab_sums[((size_t)plan.atm * sw.n_slabs + slab) * RT_NSUM + k] = v;
+    }
+}
+
+// The wavelength index CreatePhotons would assign (MC code.py:389-394) and the direction draw (:385), per photon id:
+// the emission block of the photon's stream through the same sampler the sweeps use.
+__global__ __launch_bounds__(256) void emission_kernel(const Cfg cfg, const int rng_mode, const uint32_t atm,
+                                                       const unsigned long long first_id, const long long n,
+                                                       int32_t* __restrict__ out_index, double* __restrict__ out_mu0) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long gid = first_id + (unsigned long long)i + cfg.id_base;
+    // the one-block stream takes the emission draw from words 0-1 of walk block 0, the direction from the emission block
+    const uint32_t block = rng_mode == RT_RNG_PHILOX32X4 ? 0u : kEmitBlock;
+    const PhiloxOut o = philox4x32_10((uint32_t)gid, (uint32_t)(gid >> 32), block, atm, cfg.k0, cfg.k1);
+    out_index[i] = sample_index(cfg, u52(o.w0, o.w1)) - cfg.table_base;
+    if (out_mu0) {
+        const PhiloxOut e = philox4x32_10((uint32_t)gid, (uint32_t)(gid >> 32), kEmitBlock, atm, cfg.k0, cfg.k1);
+        out_mu0[i] = cfg.rand_mu ? u52(e.w2, e.w3) : 1.0;
     }
 }
 
@@ -581,7 +179,7 @@ __global__ __launch_bounds__(kWalkBlock) void replay_kernel(const Cfg cfg, const
         const uint32_t v = wave_sum_u32(acc.c[k]);
         if (lane == 0 && v) atomicAdd(&d_counts[k], (unsigned long long)v);
     }
-    flush_hist(hist, lane, nmu, nd, 0u, 1u, d_mu_hist, d_depth);
+    flush_hist<false>(hist, lane, nmu, nd, 0u, d_mu_hist, d_depth);
 }
 
 // The kernels' own ln() and cos(2 pi u) applied element-wise (test hook).
@@ -706,79 +304,74 @@ size_t walk_lds_bytes(int n_mu_bins, int n_depth_bins) {
            sizeof(uint32_t) * kWavesPerBlock * (size_t)(n_mu_bins + 1);
 }
 
-// The instantiations.  A sweep whose flags match none of the fixed ones runs the Runtime kernel.
-typedef Fixed<RT_ORDER_MC, RT_BOUNDARY_REFLECT, RT_SCATTER_HG, true> FixedDepth;
-typedef Fixed<RT_ORDER_MC, RT_BOUNDARY_ABSORB, RT_SCATTER_HG, false> FixedAbsorb;
-typedef Fixed<RT_ORDER_MC, RT_BOUNDARY_REEMIT, RT_SCATTER_HG, false> FixedReemit;
-typedef Fixed<RT_ORDER_MC, RT_BOUNDARY_REFLECT, RT_SCATTER_ISO, false> FixedIso;
-typedef Fixed<RT_ORDER_GRAY, RT_BOUNDARY_REFLECT, RT_SCATTER_HG, false> FixedGray;
-
-typedef void (*WalkKernel)(const Cfg, const Sweep, unsigned int*, double*, unsigned long long*, unsigned long long*, double*);
-
-static WalkKernel walk_kernel_of(WalkVariant v) {
-    switch (v) {
-        case kWalkPlain: return walk_kernel<FixedBase, false, true>;
-        case kWalkBase: return walk_kernel<FixedBase, false, false>;
-        case kWalkBasePacked: return walk_kernel<FixedBase, true, false>;
-        case kWalkPlainPacked: return walk_kernel<FixedBase, true, true>;
-        case kWalkDepth: return walk_kernel<FixedDepth, false, false>;
-        case kWalkAbsorb: return walk_kernel<FixedAbsorb, false, false>;
-        case kWalkReemit: return walk_kernel<FixedReemit, false, false>;
-        case kWalkIso: return walk_kernel<FixedIso, false, false>;
-        case kWalkGray: return walk_kernel<FixedGray, false, false>;
-        case kWalkRuntimePacked: return walk_kernel<Runtime, true, false>;
-        default: return walk_kernel<Runtime, false, false>;
-    }
+// The instantiations, collected once from the translation units that hold them.
+static const std::vector<WalkVariantInfo>& walk_variants() {
+    static const std::vector<WalkVariantInfo> all = [] {
+        std::vector<WalkVariantInfo> v;
+        register_walk_base(v);  // variants 0 and 1: the run-time kernels
+        register_walk_slab_mc(v);
+        register_walk_slab_gray(v);
+        register_walk_shell(v);
+        register_walk_options(v);
+        return v;
+    }();
+    return all;
 }
 
-const char* walk_variant_name(WalkVariant v) {
-    switch (v) {
-        case kWalkPlain: return "walk_kernel<FixedBase, false, true>";
-        case kWalkBase: return "walk_kernel<FixedBase, false, false>";
-        case kWalkBasePacked: return "walk_kernel<FixedBase, true, false>";
-        case kWalkPlainPacked: return "walk_kernel<FixedBase, true, true>";
-        case kWalkDepth: return "walk_kernel<FixedDepth, false, false>";
-        case kWalkAbsorb: return "walk_kernel<FixedAbsorb, false, false>";
-        case kWalkReemit: return "walk_kernel<FixedReemit, false, false>";
-        case kWalkIso: return "walk_kernel<FixedIso, false, false>";
-        case kWalkGray: return "walk_kernel<FixedGray, false, false>";
-        case kWalkRuntimePacked: return "walk_kernel<Runtime, true, false>";
-        default: return "walk_kernel<Runtime, false, false>";
+int walk_variant_count() { return (int)walk_variants().size(); }
+const WalkVariantInfo& walk_variant(int v) { return walk_variants()[(size_t)v]; }
+
+int walk_find_variant(const WalkKey& k) {
+    const std::vector<WalkVariantInfo>& all = walk_variants();
+    for (size_t i = 0; i < all.size(); ++i) {
+        const WalkKey& q = all[i].key;
+        if (all[i].fixed && q.order == k.order && q.boundary == k.boundary && q.law == k.law && q.depth == k.depth &&
+            q.abs_only == k.abs_only && q.shell == k.shell && q.emu == k.emu && q.rng == k.rng && q.plain == k.plain)
+            return (int)i;
     }
+    return -1;
 }
 
-int walk_max_blocks_per_cu(WalkVariant v, size_t lds_bytes) {
+int walk_max_blocks_per_cu(int v, size_t lds_bytes) {
     int nb = 0;
-    const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, walk_kernel_of(v), kWalkBlock, lds_bytes);
+    const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, walk_variant(v).fn, kWalkBlock, lds_bytes);
     if (e != hipSuccess || nb < 1) nb = 1;
     return nb;
 }
 
-hipError_t launch_walk(const Cfg& cfg, const Sweep& sw, WalkVariant v, int grid, hipStream_t stream,
+hipError_t launch_walk(const Cfg& cfg, const Sweep& sw, int v, int grid, hipStream_t stream,
                        unsigned int* d_next, double* d_chunk_sums, unsigned long long* d_counts,
-                       unsigned long long* d_mu_hist, double* d_depth) {
-    const size_t lds = walk_lds_bytes(cfg.n_mu_bins, walk_variant_has_depth(v) ? cfg.n_depth_bins : 0);
-    walk_kernel_of(v)<<<grid, kWalkBlock, lds, stream>>>(cfg, sw, d_next, d_chunk_sums, d_counts, d_mu_hist, d_depth);
+                       unsigned long long* d_mu_hist, double* d_chunk_depth) {
+    const WalkVariantInfo& info = walk_variant(v);
+    const size_t lds = walk_lds_bytes(cfg.n_mu_bins, info.has_depth ? cfg.n_depth_bins : 0);
+    info.fn<<<grid, kWalkBlock, lds, stream>>>(cfg, sw, d_next, d_chunk_sums, d_counts, d_mu_hist, d_chunk_depth);
     return hipGetLastError();
 }
 
-hipError_t launch_zero_results(unsigned int* d_next, unsigned long long* d_tallies, size_t n_tallies, double* d_depth,
-                               size_t n_depth, hipStream_t stream) {
-    size_t grid = (std::max(n_tallies, n_depth) + 255) / 256;
+hipError_t launch_zero_results(unsigned int* d_next, unsigned long long* d_tallies, size_t n_tallies, hipStream_t stream) {
+    size_t grid = (n_tallies + 255) / 256;
     grid = grid < 1 ? 1 : (grid > 2048 ? 2048 : grid);
-    zero_results_kernel<<<(unsigned int)grid, 256, 0, stream>>>(d_next, d_tallies, n_tallies,
-                                                                reinterpret_cast<unsigned long long*>(d_depth), n_depth);
+    zero_results_kernel<<<(unsigned int)grid, 256, 0, stream>>>(d_next, d_tallies, n_tallies);
     return hipGetLastError();
 }
 
 hipError_t launch_finish(const Sweep& sw, const double* d_chunk_sums, double* d_slab_sums,
                          const unsigned long long* d_count_copies, unsigned long long* d_counts, size_t n_counts,
                          const unsigned long long* d_hist_copies, unsigned long long* d_mu_hist, size_t n_hist,
-                         hipStream_t stream) {
-    const size_t grid = (size_t)sw.n_atm * sw.n_slabs + (n_counts + n_hist + 63) / 64;
+                         const double* d_chunk_depth, double* d_slab_depth, int n_depth, hipStream_t stream) {
+    const size_t grid = (size_t)sw.n_atm * sw.n_slabs + (n_counts + n_hist + 63) / 64 +
+                        (size_t)sw.n_atm * sw.n_slabs * ((2 * (size_t)n_depth + 63) / 64);
     if (grid == 0 || grid > 0x7fffffffull) return grid ? hipErrorInvalidValue : hipSuccess;
     finish_kernel<<<(unsigned int)grid, 64, 0, stream>>>(sw, d_chunk_sums, d_slab_sums, d_count_copies, d_counts,
-                                                         (uint32_t)n_counts, d_hist_copies, d_mu_hist, (uint32_t)n_hist);
+                                                         (uint32_t)n_counts, d_hist_copies, d_mu_hist, (uint32_t)n_hist,
+                                                         d_chunk_depth, d_slab_depth, (uint32_t)n_depth);
+    return hipGetLastError();
+}
+
+hipError_t launch_emission(const Cfg& cfg, int rng_mode, uint32_t atm, unsigned long long first_id, long long n,
+                           int32_t* d_index, double* d_mu0, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    emission_kernel<<<(unsigned int)((n + 255) / 256), 256, 0, stream>>>(cfg, rng_mode, atm, first_id, n, d_index, d_mu0);
     return hipGetLastError();
 }
 

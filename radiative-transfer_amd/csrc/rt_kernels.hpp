@@ -53,38 +53,44 @@ constexpr int kWalkBlock = 256;
 // entries.  The limit leaves room for several workgroups per compute unit.
 size_t walk_lds_bytes(int n_mu_bins, int n_depth_bins);
 constexpr size_t kWalkLdsLimit = 64 * 1024;
-// The walk kernel's instantiations: which run flags are compile-time constants (see Fixed<> in rt_device.hpp).
-enum WalkVariant {
-    kWalkRuntime = 0,    // every flag read at run time
-    kWalkRuntimePacked,  // the same on the one-block random stream
-    kWalkPlain,          // production: MC order, reflect, HG, no depth bins; rand_mu and monochromatic off as well
-    kWalkBase,           // production flags; rand_mu / monochromatic read at run time
-    kWalkBasePacked,     // production flags on the one-block random stream
-    kWalkPlainPacked,    // the same with rand_mu and monochromatic off at compile time
-    kWalkDepth,          // production flags + depth-resolved deposition
-    kWalkAbsorb,         // absorbing lower boundary
-    kWalkReemit,         // re-emitting lower boundary
-    kWalkIso,            // scatter = 'iso'
-    kWalkGray,           // the gray script's loop order
-    kWalkVariants
+// The walk kernel's instantiations (rt_walk.hpp): which run flags are compile-time constants (see Fixed<> in
+// rt_device.hpp).  Variant 0 and 1 are the kernels that read every flag at run time (52-bit and one-block stream);
+// the others are found by their key.
+typedef void (*WalkKernel)(const Cfg, const Sweep, unsigned int*, double*, unsigned long long*, unsigned long long*, double*);
+struct WalkVariantInfo {
+    WalkKey key;
+    bool fixed;      // false: the run-time kernel
+    bool has_depth;  // the kernel contains the depth tally (and needs its LDS)
+    WalkKernel fn;
+    char name[112];
 };
-inline bool walk_variant_has_depth(WalkVariant v) { return v == kWalkRuntime || v == kWalkRuntimePacked || v == kWalkDepth; }
-const char* walk_variant_name(WalkVariant v);
-int walk_max_blocks_per_cu(WalkVariant v, size_t lds_bytes);
+constexpr int kWalkRuntime = 0, kWalkRuntimePacked = 1;
+int walk_variant_count();
+const WalkVariantInfo& walk_variant(int v);
+// the instantiation with exactly these flags fixed, or -1 (the sweep then runs a run-time kernel)
+int walk_find_variant(const WalkKey& key);
+int walk_max_blocks_per_cu(int v, size_t lds_bytes);
 
-hipError_t launch_walk(const Cfg& cfg, const Sweep& sw, WalkVariant v, int grid, hipStream_t stream,
+// d_counts / d_mu_hist: sw.n_copies copies each; d_chunk_depth: 2 * n_depth_bins doubles per chunk slot (may be null
+// when the variant has no depth tally or n_depth_bins == 0)
+hipError_t launch_walk(const Cfg& cfg, const Sweep& sw, int variant, int grid, hipStream_t stream,
                        unsigned int* d_next, double* d_chunk_sums, unsigned long long* d_counts,
-                       unsigned long long* d_mu_hist, double* d_depth);  // d_counts / d_mu_hist: sw.n_copies copies each
+                       unsigned long long* d_mu_hist, double* d_chunk_depth);
 
-// *d_next = 0, the tally copies and the depth arrays zeroed (lengths in 64-bit words; d_depth may be null with n_depth = 0)
-hipError_t launch_zero_results(unsigned int* d_next, unsigned long long* d_tallies, size_t n_tallies, double* d_depth,
-                               size_t n_depth, hipStream_t stream);
+// *d_next = 0 and the tally copies zeroed (length in 64-bit words)
+hipError_t launch_zero_results(unsigned int* d_next, unsigned long long* d_tallies, size_t n_tallies, hipStream_t stream);
 // after the walk: every slab of every atmosphere written (the owned ones from their chunk partials, the others zero)
-// and the copies of the integer tallies folded into d_counts [n_counts] and d_mu_hist [n_hist]
+// -- the ten sums to d_slab_sums [n_atm][n_slabs][RT_NSUM] and, with n_depth > 0, the depth-resolved deposition to
+// d_slab_depth [n_atm][n_slabs][2][n_depth] -- and the copies of the integer tallies folded into d_counts [n_counts]
+// and d_mu_hist [n_hist]
 hipError_t launch_finish(const Sweep& sw, const double* d_chunk_sums, double* d_slab_sums,
                          const unsigned long long* d_count_copies, unsigned long long* d_counts, size_t n_counts,
                          const unsigned long long* d_hist_copies, unsigned long long* d_mu_hist, size_t n_hist,
-                         hipStream_t stream);
+                         const double* d_chunk_depth, double* d_slab_depth, int n_depth, hipStream_t stream);
+
+// the wavelength index (and direction draw) photon ids [first_id, first_id + n) of atmosphere `atm` are emitted with
+hipError_t launch_emission(const Cfg& cfg, int rng_mode, uint32_t atm, unsigned long long first_id, long long n,
+                           int32_t* d_index, double* d_mu0, hipStream_t stream);
 
 hipError_t launch_replay(const Cfg& cfg, double tau, long long n, int max_draws, const double* d_xi,
                          const double* d_lam, const double* d_g, const double* d_albedo, const double* d_scale,

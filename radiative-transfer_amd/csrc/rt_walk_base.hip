@@ -1,0 +1,17 @@
+// Walk-kernel instantiations: the kernels that read every flag at run time, and the reference's production
+// configuration (MC code.py: reflecting floor, Henyey-Greenstein, two escape tests, no depth bins) on both random
+// streams, with and without rand_mu / monochromatic fixed off.
+#include "rt_walk.hpp"
+
+namespace rt {
+
+void register_walk_base(std::vector<WalkVariantInfo>& out) {
+    add_walk_variant<Runtime, RT_RNG_PHILOX52, false>(out);    // kWalkRuntime
+    add_walk_variant<Runtime, RT_RNG_PHILOX32X4, false>(out);  // kWalkRuntimePacked
+    add_walk_variant<FixedBase, RT_RNG_PHILOX52, true>(out);   // the headline kernel
+    add_walk_variant<FixedBase, RT_RNG_PHILOX52, false>(out);
+    add_walk_variant<FixedBase, RT_RNG_PHILOX32X4, true>(out);
+    add_walk_variant<FixedBase, RT_RNG_PHILOX32X4, false>(out);
+}
+
+}  // namespace rt

@@ -8,9 +8,8 @@ partial sums (fp64), integer tallies and escape-cosine histogram into ONE device
 tests): the integer tallies add as integers, and every slab entry is non-zero on exactly one rank
 and all-zero bits elsewhere, so adding the bit patterns returns that rank's double unchanged.  The
 final sum over the slab axis is done in slab order on every rank.  The result is bit-for-bit the
-same for 1, 2, 4 or 8 ranks.  Depth-resolved deposition (``n_depth_bins > 0``) is accumulated with
-floating-point atomics on every rank, so it needs a floating-point sum of its own: a second, fp64
-all-reduce that only runs when depth bins are requested.
+same for 1, 2, 4 or 8 ranks.  Depth-resolved deposition (``n_depth_bins > 0``) travels the same way:
+per slab, in the same buffer, as bit patterns.
 torch is used for device buffers and the collective only.
 """
 import numpy as np
@@ -20,22 +19,26 @@ from .engine import SweepResult, make_params
 
 
 class TallyBuffer:
-    """Slab sums, counts and escape-cosine histogram of one sweep in one int64 tensor.
+    """Slab sums, counts, escape-cosine histogram and per-slab depth bins of one sweep in one int64 tensor.
 
-    Layout (64-bit words): [n_atm][n_slabs][NSUM] doubles | [n_atm][NCNT] u64 | [n_atm][n_mu_bins+1] u64.
-    ``words`` is what the collective sees; ``slab``, ``counts`` and ``hist`` are views of it."""
+    Layout (64-bit words): [n_atm][n_slabs][NSUM] doubles | [n_atm][NCNT] u64 | [n_atm][n_mu_bins+1] u64 |
+    [n_atm][n_slabs][2][n_depth_bins] doubles.
+    ``words`` is what the collective sees; ``slab``, ``counts``, ``hist`` and ``depth`` are views of it."""
 
-    def __init__(self, torch, n_atm, n_slabs, n_mu_bins, device):
-        self.shape = (n_atm, n_slabs, n_mu_bins)
+    def __init__(self, torch, n_atm, n_slabs, n_mu_bins, device, n_depth_bins=0):
+        self.shape = (n_atm, n_slabs, n_mu_bins, n_depth_bins)
         n_slab, n_cnt, n_hist = n_atm * n_slabs * abi.NSUM, n_atm * abi.NCNT, n_atm * (n_mu_bins + 1)
-        self.words = torch.zeros(n_slab + n_cnt + n_hist, dtype=torch.int64, device=device)
+        n_depth = n_atm * n_slabs * 2 * n_depth_bins
+        self.words = torch.zeros(n_slab + n_cnt + n_hist + n_depth, dtype=torch.int64, device=device)
         self.slab = self.words[:n_slab].view(torch.float64)
         self.counts = self.words[n_slab:n_slab + n_cnt]
-        self.hist = self.words[n_slab + n_cnt:]
+        self.hist = self.words[n_slab + n_cnt:n_slab + n_cnt + n_hist]
+        self.depth = self.words[n_slab + n_cnt + n_hist:].view(torch.float64) if n_depth else None
 
     def pointers(self):
-        """Device addresses of the three parts, as rt_run_device wants them."""
-        return self.slab.data_ptr(), self.counts.data_ptr(), self.hist.data_ptr()
+        """Device addresses of the four parts, as rt_run_device wants them (the last is None without depth bins)."""
+        return (self.slab.data_ptr(), self.counts.data_ptr(), self.hist.data_ptr(),
+                None if self.depth is None else self.depth.data_ptr())
 
     def all_reduce(self, group=None):
         """The run's only collective (no-op for a single process).  With the gloo backend (CPU rehearsal of
@@ -50,23 +53,11 @@ class TallyBuffer:
         else:
             dist.all_reduce(self.words, op=dist.ReduceOp.SUM, group=group)
 
-    def result(self, depth=None, n_depth_bins=0):
-        n_atm, n_slabs, n_mu_bins = self.shape
+    def result(self):
+        n_atm, n_slabs, n_mu_bins, n_depth_bins = self.shape
         return result_from_arrays(self.slab.cpu().numpy(), self.counts.cpu().numpy(), self.hist.cpu().numpy(),
-                                  None if depth is None else depth.cpu().numpy(), n_atm, n_mu_bins, n_depth_bins, n_slabs)
-
-
-def all_reduce_depth(depth, group=None):
-    """Floating-point sum of the depth-resolved deposition over the ranks (only with n_depth_bins > 0)."""
-    import torch.distributed as dist
-    if depth is None or not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
-        return
-    if depth.is_cuda and dist.get_backend(group) == "gloo":
-        host = depth.cpu()
-        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
-        depth.copy_(host)
-    else:
-        dist.all_reduce(depth, op=dist.ReduceOp.SUM, group=group)
+                                  None if self.depth is None else self.depth.cpu().numpy(), n_atm, n_mu_bins,
+                                  n_depth_bins, n_slabs)
 
 
 def result_from_arrays(slab_sums, counts, mu_hist, depth, n_atm, n_mu_bins, n_depth_bins, n_slabs):
@@ -74,10 +65,13 @@ def result_from_arrays(slab_sums, counts, mu_hist, depth, n_atm, n_mu_bins, n_de
     res.slab_sums[...] = np.asarray(slab_sums, dtype=np.float64).reshape(n_atm, n_slabs, abi.NSUM)
     res.counts[...] = np.asarray(counts).reshape(n_atm, abi.NCNT).astype(np.uint64)
     res.mu_hist[...] = np.asarray(mu_hist).reshape(n_atm, n_mu_bins + 1).astype(np.uint64)
-    if n_depth_bins:
-        d = np.asarray(depth, dtype=np.float64).reshape(-1)[:2 * n_atm * n_depth_bins].reshape(2, n_atm, n_depth_bins)
-        res.depth_momentum[...] = d[0]
-        res.depth_energy[...] = d[1]
+    if n_depth_bins:  # [n_atm][n_slabs][2][n_depth_bins]: the slab axis added in index order, like the sums
+        d = np.asarray(depth, dtype=np.float64).reshape(n_atm, n_slabs, 2, n_depth_bins)
+        tot = np.zeros((n_atm, 2, n_depth_bins))
+        for s in range(n_slabs):
+            tot += d[:, s]
+        res.depth_momentum[...] = tot[:, 0]
+        res.depth_energy[...] = tot[:, 1]
     res.finalize_from_slabs()
     return res
 
@@ -99,24 +93,21 @@ class DistributedSweep:
     def _buffers(self, n_atm, n_slabs, n_mu_bins, n_depth_bins):
         key = (n_atm, n_slabs, n_mu_bins, n_depth_bins)
         if key not in self._bufs:
-            t = self.torch
-            self._bufs[key] = (TallyBuffer(t, n_atm, n_slabs, n_mu_bins, self.device),
-                               t.zeros(2 * n_atm * n_depth_bins, dtype=t.float64, device=self.device) if n_depth_bins else None)
+            self._bufs[key] = TallyBuffer(self.torch, n_atm, n_slabs, n_mu_bins, self.device, n_depth_bins)
         return self._bufs[key]
 
     def enqueue(self, tau, n_photons, n_slabs=8, **kw):
-        """Launch the sweep for this rank's slabs and the all-reduce; returns the device buffers."""
+        """Launch the sweep for this rank's slabs and the all-reduce; returns the device buffer."""
         if n_slabs % self.world:
             raise ValueError(f"n_slabs ({n_slabs}) must be a multiple of the number of ranks ({self.world})")
         prm = make_params(tau, n_photons, n_slabs=n_slabs, rank=self.rank, world=self.world, **kw)
-        buf, depth = self._buffers(prm.n_atm, n_slabs, prm.n_mu_bins, prm.n_depth_bins)
+        buf = self._buffers(prm.n_atm, n_slabs, prm.n_mu_bins, prm.n_depth_bins)
         stream = self.torch.cuda.current_stream(self.device).cuda_stream
-        self.engine.run_device(prm, *buf.pointers(), depth.data_ptr() if depth is not None else None, stream)
+        self.engine.run_device(prm, *buf.pointers(), stream)
         buf.all_reduce(self.group)
-        all_reduce_depth(depth, self.group)
-        return prm, (buf, depth)
+        return prm, buf
 
     def run(self, tau, n_photons, n_slabs=8, **kw):
-        prm, (buf, depth) = self.enqueue(tau, n_photons, n_slabs, **kw)
+        prm, buf = self.enqueue(tau, n_photons, n_slabs, **kw)
         self.torch.cuda.synchronize(self.device)
-        return buf.result(depth, prm.n_depth_bins)
+        return buf.result()

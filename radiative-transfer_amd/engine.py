@@ -91,13 +91,15 @@ class SweepResult:
 def make_params(tau, n_photons, *, boundary="reflect", scatter="hg", order="mc", rand_mu=0, abs_only=0,
                 n_mu_bins=10, n_depth_bins=0, max_events=0, n_slabs=8, rank=0, world=1, seed=DEFAULT_SEED,
                 photon_id_base=0, monochromatic=0.0, alpha=0.3, h=H_PLANCK, rng="philox52", table_of_atm=None,
-                geometry="slab", shell_inner=0.0, escaped_mu=False):
+                geometry="slab", shell_inner=0.0, escaped_mu=False, runtime_kernel=False):
     """rng: "philox52" (default; 52-bit uniforms, two Philox blocks per loop iteration) or "philox32x4" (one
     block per iteration, 32-bit uniforms; faster, see rt_rng_mode in include/rt_amd.h).
     geometry: "slab" (the reference's) or "shell", a uniform spherical shell whose inner radius is `shell_inner`
     thicknesses (see RT_GEOM_SHELL in include/rt_amd.h; use SweepResult.deposited_fraction() for its result).
     escaped_mu: True asks Engine.run for the escape cosine of every photon (SweepResult.escaped_mu); an integer is taken
-    as the address of a caller-owned DEVICE array for Engine.run_device (rt_params.escaped_mu)."""
+    as the address of a caller-owned DEVICE array for Engine.run_device (rt_params.escaped_mu).
+    runtime_kernel: walk with the kernel that reads every option at run time even where one with these options fixed at
+    compile time exists (RT_FLAG_RUNTIME_KERNEL; same results, for testing one against the other)."""
     if geometry not in abi.GEOMETRY:
         raise ValueError(f"geometry must be one of {sorted(abi.GEOMETRY)}")
     if rng not in abi.RNG:
@@ -109,10 +111,14 @@ def make_params(tau, n_photons, *, boundary="reflect", scatter="hg", order="mc",
         raise ValueError(f"scatter must be one of {sorted(abi.SCATTER)}")
     tau = np.ascontiguousarray(np.atleast_1d(tau), dtype=np.float64)
     npn = np.ascontiguousarray(np.broadcast_to(np.atleast_1d(n_photons), tau.shape), dtype=np.uint64)
-    p = abi.RtParams(len(tau), abi.BOUNDARY[boundary], abi.SCATTER[scatter], abi.ORDER[order], int(rand_mu),
-                     int(abs_only), int(n_mu_bins), int(n_depth_bins), int(max_events), int(n_slabs), int(rank),
-                     int(world), int(seed), int(photon_id_base), float(monochromatic), float(alpha), float(h),
-                     _dp(tau), _u64p(npn), abi.RNG[rng], abi.GEOMETRY[geometry], None, float(shell_inner))
+    p = abi.RtParams(struct_size=C.sizeof(abi.RtParams), n_atm=len(tau), boundary=abi.BOUNDARY[boundary],
+                     scatter=abi.SCATTER[scatter], loop_order=abi.ORDER[order], rand_mu=int(rand_mu), abs_only=int(abs_only),
+                     n_mu_bins=int(n_mu_bins), n_depth_bins=int(n_depth_bins), max_events_per_photon=int(max_events),
+                     n_slabs=int(n_slabs), rank=int(rank), world=int(world), seed=int(seed),
+                     photon_id_base=int(photon_id_base), monochromatic_wl=float(monochromatic), alpha=float(alpha),
+                     h=float(h), tau_atm=_dp(tau), n_photons=_u64p(npn), rng_mode=abi.RNG[rng],
+                     geometry=abi.GEOMETRY[geometry], shell_inner=float(shell_inner),
+                     flags=abi.FLAG_RUNTIME_KERNEL if runtime_kernel else 0)
     p._keep = (tau, npn)
     p._want_escaped_mu = escaped_mu is True
     if escaped_mu is not True and escaped_mu:
@@ -189,8 +195,9 @@ class Engine:
         return res
 
     def run_device(self, params, slab_sums_ptr, counts_ptr, mu_hist_ptr, depth_ptr=None, stream=None, static=False):
-        """Enqueue a sweep whose results stay in caller-owned device buffers (raw addresses).  `static`: the entry
-        point that allocates nothing (rt_run_device_static: work memory in the library's static device array)."""
+        """Enqueue a sweep whose results stay in caller-owned device buffers (raw addresses; depth_ptr:
+        [n_atm][n_slabs][2][n_depth_bins] doubles).  `static`: the entry point that allocates nothing
+        (rt_run_device_static: work memory in the library's static device array)."""
         fn = self._lib.rt_run_device_static if static else self._lib.rt_run_device
         self._check(fn(self._ctx, C.byref(params), C.c_void_p(slab_sums_ptr),
                                             C.c_void_p(counts_ptr), C.c_void_p(mu_hist_ptr),
@@ -210,11 +217,21 @@ class Engine:
     def comm_destroy(self):
         self._check(self._lib.rt_comm_destroy(self._ctx))
 
-    def run_allreduce(self, params, tallies_ptr, depth_ptr=None, stream=None):
+    def run_allreduce(self, params, tallies_ptr, stream=None):
         """Sweep of this rank's slabs + one all-reduce of the packed tally buffer (layout: distributed.TallyBuffer)."""
         self._check(self._lib.rt_run_allreduce(self._ctx, C.byref(params), C.c_void_p(tallies_ptr),
-                                               C.c_void_p(depth_ptr) if depth_ptr else None,
                                                C.c_void_p(stream) if stream else None))
+
+    def emission_indices(self, params, atm, n, first_id=0, with_mu0=False):
+        """Index into the table's wavelengths (and, with_mu0, the starting cosine) that the sweeps give photon ids
+        first_id .. first_id + n - 1 of atmosphere `atm`: the stand-in for CreatePhotons' wavelength draw
+        (MC code.py:389-394)."""
+        idx = np.zeros(int(n), dtype=np.int32)
+        mu0 = np.zeros(int(n)) if with_mu0 else None
+        self._check(self._lib.rt_emission_indices(self._ctx, C.byref(params), int(atm), int(first_id), int(n),
+                                                  idx.ctypes.data_as(C.POINTER(C.c_int32)),
+                                                  None if mu0 is None else _dp(mu0)))
+        return (idx, mu0) if with_mu0 else idx
 
     def replay(self, params, xi, lam, g, albedo, scale, mu0):
         xi = np.ascontiguousarray(xi, dtype=np.float64)

@@ -195,7 +195,7 @@ def save_mc_column(path, tau_list, time_slice, momentum_transfer):
         header = header + [name]
         rows = [r + [v] for r, v in zip(rows, vals)]
     with open(path, "w", newline="") as fh:
-        w = csv.writer(fh)
+        w = csv.writer(fh, lineterminator="\n")  # pandas' to_csv ends lines with os.linesep's "\n", csv's default is "\r\n"
         w.writerow(header)
         w.writerows(rows)
 

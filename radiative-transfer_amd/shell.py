@@ -136,7 +136,8 @@ class ShellModel:
     def c_struct(self, n_regions=0):
         n_l = 0 if self.l_ages is None else len(self.l_ages)
         gal = None if self.galaxy is None else self.galaxy.c_struct(n_regions)
-        m = abi.RtShellModel(int(self.stellar_aging), int(self.static_momentum), len(self.mc_tau), len(self.mc_ages), n_l, 0,
+        m = abi.RtShellModel(int(self.stellar_aging), int(self.static_momentum), len(self.mc_tau), len(self.mc_ages), n_l,
+                             C.sizeof(abi.RtShellModel),
                              G_NEWTON, C_LIGHT, SIGMA_SB, YEAR_S, self.h_Hi * CM_PC, 10000 * CM_PC, self.time_slice,
                              self.tau_cutoff, self._l_norm(), _dp(self.mc_tau), _dp(self.mc_ages), _dp(self.mc_values),
                              None if self.l_ages is None else _dp(self.l_ages),

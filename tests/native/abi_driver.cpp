@@ -34,6 +34,7 @@ struct Sweep {
     rt_params p;
     Sweep(std::vector<double> t, uint64_t photons) : tau(std::move(t)), n(tau.size(), photons) {
         std::memset(&p, 0, sizeof p);
+        p.struct_size = sizeof p;
         p.n_atm = (int32_t)tau.size();
         p.n_mu_bins = 10;
         p.n_slabs = 8;
@@ -111,6 +112,11 @@ int main() {
         CHECK(rt_run(ctx, &s.p, &r.t) == RT_ERR_STATE, "run before tables must be RT_ERR_STATE");
         CHECK(std::strlen(rt_last_error()) > 0, "no message");
         CHECK(rt_run(ctx, nullptr, &r.t) == RT_ERR_INVALID, "NULL params");
+        {   // a struct typed from an older header: its first word is n_atm, not a size -- refused before anything else is read
+            Sweep old({1.0}, 100);
+            old.p.struct_size = 1;
+            CHECK(rt_run(ctx, &old.p, &r.t) == RT_ERR_INVALID && std::strstr(rt_last_error(), "struct_size"), "stale rt_params must be refused");
+        }
         CHECK(rt_run(nullptr, &s.p, &r.t) == RT_ERR_INVALID, "NULL ctx");
     }
     std::vector<double> wl, g, alb, sc, pdf;
@@ -227,7 +233,7 @@ int main() {
         unsigned char id[RT_COMM_ID_BYTES];
         if (rt_comm_unique_id(id) == RT_OK) {
             OK(rt_comm_init(ctx, 0, 1, id));
-            OK(rt_run_allreduce(ctx, &s.p, d2, nullptr, nullptr));
+            OK(rt_run_allreduce(ctx, &s.p, d2, nullptr));
             HIP(hipDeviceSynchronize());
             HIP(hipMemcpy(h2.data(), d2, 8 * words, hipMemcpyDeviceToHost));
             CHECK(h2 == h1, "all-reduce over one rank changed the tallies");
@@ -288,6 +294,7 @@ int main() {
         const double cm_pc = 3.086e18;
         rt_shell_model m;
         std::memset(&m, 0, sizeof m);
+        m.struct_size = sizeof m;
         m.n_tau = 4; m.n_age = 2; m.n_lage = 3;
         m.G = 6.67259e-8; m.c = 2.99792458e10; m.sigma_sb = 5.67037441918443e-5; m.year_s = 31556952.0;
         m.h_hi_cm = 100 * cm_pc; m.r_escape = 10000 * cm_pc; m.time_slice = 6.0; m.l_norm = 1.0;

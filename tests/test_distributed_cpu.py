@@ -1,6 +1,6 @@
 """The N > 1 path on CPU: two gloo ranks each own half of the slabs (here filled by the CPU oracle, which
 honours rank / world exactly like the kernel), all-reduce the tallies with the product's own combine code --
-one int64 buffer holding the doubles' bit patterns, the counts and the histogram, one collective -- and must
+one int64 buffer holding the doubles' bit patterns (slab sums and per-slab depth bins), the counts and the histogram, one collective -- and must
 reproduce the single-rank result bit for bit."""
 import importlib
 import os
@@ -34,6 +34,19 @@ N_PHOTONS = 4001  # not a multiple of the slab count on purpose
 KW = dict(n_mu_bins=10, n_depth_bins=4, n_slabs=8)
 
 
+def _fill(buf, c_oracle, slabs):
+    """The packed buffer as the sweep of a rank that owns `slabs` leaves it: the CPU oracle walks one slab at a time
+    (as rank s of 8), so that the depth bins are known per slab as on the device."""
+    for s in slabs:
+        t = c_oracle.run(c_oracle.make_params(TAU, N_PHOTONS, rank=s, world=8, **KW), *_table())
+        buf.slab += torch.from_numpy(t.slab_sums.reshape(-1).copy())       # slab s is the only non-zero one
+        buf.counts += torch.from_numpy(t.counts.astype(np.int64).reshape(-1).copy())
+        buf.hist += torch.from_numpy(t.mu_hist.astype(np.int64).reshape(-1).copy())
+        d = buf.depth.view(len(TAU), 8, 2, 4)
+        d[:, s, 0] = torch.from_numpy(t.depth_momentum.copy())
+        d[:, s, 1] = torch.from_numpy(t.depth_energy.copy())
+
+
 def _worker(rank, world, port, out_path):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -41,24 +54,18 @@ def _worker(rank, world, port, out_path):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from oracle import c_oracle
     D = importlib.import_module("radiative-transfer_amd.distributed")
-    A = importlib.import_module("radiative-transfer_amd._abi")
-    t = c_oracle.run(c_oracle.make_params(TAU, N_PHOTONS, rank=rank, world=world, **KW), *_table())
     # the product's own packed buffer (one int64 tensor, one collective), here on the CPU
-    buf = D.TallyBuffer(torch, len(TAU), 8, 10, "cpu")
-    buf.slab.copy_(torch.from_numpy(t.slab_sums.reshape(-1).copy()))
-    buf.counts.copy_(torch.from_numpy(t.counts.astype(np.int64).reshape(-1).copy()))
-    buf.hist.copy_(torch.from_numpy(t.mu_hist.astype(np.int64).reshape(-1).copy()))
-    depth = torch.from_numpy(np.stack([t.depth_momentum, t.depth_energy]).reshape(-1).copy())
+    buf = D.TallyBuffer(torch, len(TAU), 8, 10, "cpu", 4)
+    _fill(buf, c_oracle, [s for s in range(8) if s % world == rank])
     calls = []
     real = dist.all_reduce
     dist.all_reduce = lambda *a, **k: (calls.append(a[0].dtype), real(*a, **k))[1]
     buf.all_reduce()
-    assert calls == [torch.int64]            # ONE collective for sums, counts and histogram
-    D.all_reduce_depth(depth)
     dist.all_reduce = real
-    res = buf.result(depth, 4)
+    assert calls == [torch.int64]            # ONE collective for sums, counts, histogram and depth bins
+    res = buf.result()
     np.savez(out_path % rank, sums=res.sums, slab=res.slab_sums, counts=res.counts, hist=res.mu_hist,
-             dm=res.depth_momentum)
+             dm=res.depth_momentum, de=res.depth_energy)
     dist.destroy_process_group()
 
 
@@ -70,14 +77,20 @@ def test_two_ranks_match_one_rank(tmp_path, c_oracle):
     for k in r0.files:
         assert np.array_equal(r0[k], r1[k])  # every rank holds the full result
     D = importlib.import_module("radiative-transfer_amd.distributed")
-    t = c_oracle.run(c_oracle.make_params(TAU, N_PHOTONS, **KW), *_table())
-    one = D.result_from_arrays(t.slab_sums, t.counts, t.mu_hist, np.stack([t.depth_momentum, t.depth_energy]),
-                               len(TAU), 10, 4, 8)
+    whole = D.TallyBuffer(torch, len(TAU), 8, 10, "cpu", 4)
+    _fill(whole, c_oracle, range(8))
+    one = whole.result()
     assert np.array_equal(r0["slab"], one.slab_sums)     # bitwise: x + 0 is exact
     assert np.array_equal(r0["sums"], one.sums)          # same slab-order summation
     assert np.array_equal(r0["counts"], one.counts)
     assert np.array_equal(r0["hist"], one.mu_hist)
-    np.testing.assert_allclose(r0["dm"], one.depth_momentum, rtol=1e-13, atol=0)
+    assert np.array_equal(r0["dm"], one.depth_momentum) and np.array_equal(r0["de"], one.depth_energy)
+    # ... and the slab-wise result is the one-process result
+    t = c_oracle.run(c_oracle.make_params(TAU, N_PHOTONS, **KW), *_table())
+    assert np.array_equal(one.counts, t.counts) and np.array_equal(one.mu_hist, t.mu_hist)
+    np.testing.assert_allclose(one.sums, t.sums, rtol=1e-13, atol=0)
+    np.testing.assert_allclose(one.depth_momentum, t.depth_momentum, rtol=1e-13, atol=0)
+    np.testing.assert_allclose(one.depth_energy, t.depth_energy, rtol=1e-13, atol=0)
     assert int(one.counts[:, c_oracle.abi.CNT_PHOTONS].sum()) == 2 * N_PHOTONS
 
 

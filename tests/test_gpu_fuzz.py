@@ -3,7 +3,7 @@
 The named tests cover each option on its own and the pairs the reference uses; this one draws whole
 configurations -- boundary x scattering law x loop order x geometry x stream x bins x slabs x rank x tables x
 photon counts x id base x seed x iteration cap -- so that options meet in combinations nobody listed, in the
-kernels with flags fixed at compile time and in the run-time one alike.  Integer tallies exact, sums to 1e-12.
+kernels with flags fixed at compile time and (three cases in ten are sent there whatever their flags) in the run-time one alike.  Integer tallies exact, sums to 1e-12.
 """
 import numpy as np
 import pytest
@@ -45,17 +45,19 @@ def draw_case(k):
     if multi:
         kw["table_of_atm"] = rs.randint(0, 3, n_atm)
     mono = rs.rand() < 0.2
-    return kw, tau, n_photons, multi, mono
+    runtime = rs.rand() < 0.3  # (drawn last: the cases keep the options they had before this one existed)
+    return kw, tau, n_photons, multi, mono, runtime
 
 
 @pytest.mark.parametrize("k", range(N_CASES))
 def test_random_configuration(rt, engine, c_oracle, k):
-    kw, tau, n_photons, multi, mono = draw_case(k)
+    kw, tau, n_photons, multi, mono, runtime = draw_case(k)
     wl, g, alb, scale, pdf = tables3() if multi else small_table()
     if mono:
         kw["monochromatic"] = float(wl[17])
     engine.set_tables(wl, g, alb, scale, pdf)
-    res = engine.run(rt.make_params(tau, n_photons, **kw))
+    res = engine.run(rt.make_params(tau, n_photons, runtime_kernel=runtime, **kw))
+    assert ("<runtime" in engine.last_kernel()) or not runtime
     ref = c_oracle.run(c_oracle.make_params(tau, n_photons, **kw), wl, g, alb, scale, pdf)
     # shell geometry: sums of signed terms can cancel, same bound as the tests of that mode
     compare(res, ref, rt._abi, nd=kw["n_depth_bins"], floor=1e-14 if kw.get("geometry") == "shell" else 0.0)

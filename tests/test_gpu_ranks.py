@@ -35,7 +35,8 @@ wl = np.round(np.linspace(0.1, 1.0, n), 4)
 eng = rt.Engine(dev)
 eng.set_tables(wl, np.linspace(0.3, 0.8, n), np.linspace(0.4, 0.9, n), np.linspace(2.0, 0.5, n), np.linspace(1.0, 0.1, n) / n)
 res = D.DistributedSweep(eng).run(np.array([0.05, 0.7, 9.0]), 300007, n_mu_bins=10, n_depth_bins=4)
-np.savez(out % rank, sums=res.sums, slab=res.slab_sums, counts=res.counts, hist=res.mu_hist, dm=res.depth_momentum)
+np.savez(out % rank, sums=res.sums, slab=res.slab_sums, counts=res.counts, hist=res.mu_hist, dm=res.depth_momentum,
+         de=res.depth_energy)
 dist.destroy_process_group()
 eng.close()
 """
@@ -69,13 +70,20 @@ def _single(rt, engine):
     return engine.run(rt.make_params(np.array([0.05, 0.7, 9.0]), 300007, n_mu_bins=10, n_depth_bins=4))
 
 
-@pytest.mark.parametrize("world", [2, 4])
+def _same_bits(r, one):
+    assert np.array_equal(r["slab"], one.slab_sums) and np.array_equal(r["sums"], one.sums)
+    assert np.array_equal(r["counts"], one.counts) and np.array_equal(r["hist"], one.mu_hist)
+    # the depth-resolved deposition travels per slab in the same buffer: the same bits for any number of ranks
+    assert np.array_equal(r["dm"], one.depth_momentum) and np.array_equal(r["de"], one.depth_energy)
+    assert np.any(one.depth_momentum != 0) and np.any(one.depth_energy != 0)
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_ranks_sharing_one_gpu_match_one_rank(rt, engine, tmp_path, world):
+    """world = 8 is the share of an 8-GPU job: every rank walks exactly one slab of every atmosphere."""
     one = _single(rt, engine)
     for r in _run_ranks(world, "gloo", tmp_path):
-        assert np.array_equal(r["slab"], one.slab_sums) and np.array_equal(r["sums"], one.sums)
-        assert np.array_equal(r["counts"], one.counts) and np.array_equal(r["hist"], one.mu_hist)
-        np.testing.assert_allclose(r["dm"], one.depth_momentum, rtol=1e-12)
+        _same_bits(r, one)
 
 
 def test_two_gpus_over_rccl_match_one_rank(rt, engine, tmp_path):
@@ -84,8 +92,7 @@ def test_two_gpus_over_rccl_match_one_rank(rt, engine, tmp_path):
         pytest.skip("needs two GPUs")
     one = _single(rt, engine)
     for r in _run_ranks(2, "nccl", tmp_path):
-        assert np.array_equal(r["slab"], one.slab_sums) and np.array_equal(r["sums"], one.sums)
-        assert np.array_equal(r["counts"], one.counts) and np.array_equal(r["hist"], one.mu_hist)
+        _same_bits(r, one)
 
 
 def _bench(*args):
@@ -137,12 +144,12 @@ wl = np.round(np.linspace(0.1, 1.0, n), 4)
 eng.set_tables(wl, np.linspace(0.3, 0.8, n), np.linspace(0.4, 0.9, n), np.linspace(2.0, 0.5, n), np.linspace(1.0, 0.1, n) / n)
 tau = np.array([0.05, 0.7, 9.0])
 prm = rt.make_params(tau, 300007, n_mu_bins=10, n_depth_bins=4)     # rank / world come from the communicator
-buf = D.TallyBuffer(torch, len(tau), 8, 10, torch.device("cuda", dev))
-depth = torch.zeros(2 * len(tau) * 4, dtype=torch.float64, device=buf.words.device)
-eng.run_allreduce(prm, buf.words.data_ptr(), depth.data_ptr(), torch.cuda.current_stream().cuda_stream)
+buf = D.TallyBuffer(torch, len(tau), 8, 10, torch.device("cuda", dev), 4)
+eng.run_allreduce(prm, buf.words.data_ptr(), torch.cuda.current_stream().cuda_stream)
 torch.cuda.synchronize()
-res = buf.result(depth, 4)
-np.savez(out % rank, sums=res.sums, slab=res.slab_sums, counts=res.counts, hist=res.mu_hist, dm=res.depth_momentum)
+res = buf.result()
+np.savez(out % rank, sums=res.sums, slab=res.slab_sums, counts=res.counts, hist=res.mu_hist, dm=res.depth_momentum,
+         de=res.depth_energy)
 eng.comm_destroy()
 eng.close()
 """
@@ -165,9 +172,7 @@ def test_library_collective_single_rank(rt, engine, tmp_path):
     uses (RCCL opened by the library, packed buffer, all-reduce on the sweep's stream), equal to rt_run bit for bit."""
     one = _single(rt, engine)
     (r,) = _run_comm_ranks(1, tmp_path)
-    assert np.array_equal(r["slab"], one.slab_sums) and np.array_equal(r["sums"], one.sums)
-    assert np.array_equal(r["counts"], one.counts) and np.array_equal(r["hist"], one.mu_hist)
-    np.testing.assert_allclose(r["dm"], one.depth_momentum, rtol=1e-12)
+    _same_bits(r, one)
 
 
 def test_library_collective_two_gpus(rt, engine, tmp_path):
@@ -176,5 +181,4 @@ def test_library_collective_two_gpus(rt, engine, tmp_path):
         pytest.skip("needs two GPUs")
     one = _single(rt, engine)
     for r in _run_comm_ranks(2, tmp_path):
-        assert np.array_equal(r["slab"], one.slab_sums) and np.array_equal(r["sums"], one.sums)
-        assert np.array_equal(r["counts"], one.counts) and np.array_equal(r["hist"], one.mu_hist)
+        _same_bits(r, one)

@@ -83,7 +83,7 @@ def test_production_sweep_matches_reference_where_the_streams_coincide(rt, engin
     atmosphere 0 and the case's seed: exactly what the PRODUCTION sweep draws for photon ids 0..n-1 of atmosphere 0
     under that seed on a one-wavelength table.  So the production kernels (not the replay kernel) must return the
     reference's own numbers, with no restatement in between -- the kernel with the case's flags fixed at compile
-    time where there is one, and the run-time-flag kernel (asked for through the per-photon cosines)."""
+    time where there is one (with and without the per-photon cosines), and the run-time-flag kernel."""
     c = case(name)
     n, seed, order = int(c["n"]), int(c["seed"]), str(c["order"])
     gray = order == "gray"
@@ -93,8 +93,8 @@ def test_production_sweep_matches_reference_where_the_streams_coincide(rt, engin
               abs_only=int(c["abs_only"]), n_mu_bins=10)
     fates = np.bincount(c["ref_fate"], minlength=6)
     kernels = set()
-    for per_photon in (False, True):
-        res = engine.run(rt.make_params(float(c["tau"]), n, escaped_mu=per_photon, **kw))
+    for per_photon, runtime in ((False, False), (True, False), (True, True)):
+        res = engine.run(rt.make_params(float(c["tau"]), n, escaped_mu=per_photon, runtime_kernel=runtime, **kw))
         kernels.add(engine.last_kernel())
         s, cnt = res.sums[0], res.counts[0].astype(np.int64)
         np.testing.assert_allclose(s[A.SUM_INITIAL], float(c["ref_initial_momentum"]), rtol=RTOL)
@@ -110,9 +110,9 @@ def test_production_sweep_matches_reference_where_the_streams_coincide(rt, engin
         assert np.array_equal(res.mu_hist[0], ref_hist)
         if per_photon:   # the reference's escaped_mu list itself (it appends in escape order: compare as sorted lists)
             np.testing.assert_allclose(np.sort(res.escaped_mu[0]), np.sort(c["ref_escaped_mu"]), rtol=0, atol=1e-12)
-    assert any("Runtime" in k for k in kernels), kernels
-    if name.startswith("mcu_") and not int(c["abs_only"]):   # these flag sets all have a kernel of their own
-        assert len(kernels) == 2, kernels
+    assert "walk_kernel<runtime>" in kernels, kernels
+    if name.startswith("mcu_"):   # these flag sets all have a kernel of their own
+        assert len(kernels) >= 2, kernels
 
 
 def test_the_headline_kernel_is_among_them(rt, engine):
@@ -120,7 +120,7 @@ def test_the_headline_kernel_is_among_them(rt, engine):
     c = case("mcu_reflect_hg_tau3")
     engine.set_tables([float(c["lam"][0])], [float(c["g"][0])], [float(c["albedo"][0])], [float(c["scale"][0])])
     engine.run(rt.make_params(float(c["tau"]), int(c["n"]), seed=int(c["seed"]), n_mu_bins=10))
-    assert engine.last_kernel() == "walk_kernel<FixedBase, false, true>"
+    assert engine.last_kernel() == "walk_kernel<mc,reflect,hg,plain>"
     assert len(UNIFORM) == 12
 
 

@@ -185,21 +185,34 @@ def test_device_math_accuracy(engine):
 
 
 def test_which_kernel_serves_which_flags(rt, engine):
-    """Depth bins, the other boundaries, isotropic scattering and the gray loop order each have a kernel with those
-    flags fixed at compile time (the lean loop of the production kernel); only combinations without one -- abs_only,
-    the Draine laws, the shell geometry, two options at once -- run the kernel that reads every flag at run time."""
+    """Every slab combination of loop order x boundary x {hg, iso} x depth bins, the shell geometry and the exact
+    Draine law with every boundary and depth bins, abs_only and the per-photon escape cosines have a kernel with those
+    flags fixed at compile time (the lean loop of the production kernel); what is left -- the reference's own Draine
+    sampler, options on the one-block stream, pairs of the rarer options -- runs the kernel that reads every flag at
+    run time, and RT_FLAG_RUNTIME_KERNEL asks for that kernel outright."""
     engine.set_tables(*small_table())
     tau = np.array([0.5, 5.0])
-    want = [(dict(), "FixedBase, false, true"), (dict(rand_mu=1), "FixedBase, false, false"),
-            (dict(rng="philox32x4"), "FixedBase, true, true"), (dict(rng="philox32x4", rand_mu=1), "FixedBase, true, false"),
-            (dict(n_depth_bins=8), "FixedDepth"),
-            (dict(boundary="absorb"), "FixedAbsorb"), (dict(boundary="reemit"), "FixedReemit"),
-            (dict(scatter="iso"), "FixedIso"), (dict(order="gray", h=1.0), "FixedGray"),
-            (dict(abs_only=1), "Runtime, false"), (dict(boundary="absorb", n_depth_bins=8), "Runtime, false"),
-            (dict(geometry="shell", shell_inner=1.0), "Runtime, false"), (dict(scatter="iso", rng="philox32x4"), "Runtime, true")]
+    want = [(dict(), "<mc,reflect,hg,plain>"), (dict(rand_mu=1), "<mc,reflect,hg>"),
+            (dict(rng="philox32x4"), "<mc,reflect,hg,philox32x4,plain>"), (dict(rng="philox32x4", rand_mu=1), "<mc,reflect,hg,philox32x4>"),
+            (dict(n_depth_bins=8), "<mc,reflect,hg,depth>"),
+            (dict(boundary="absorb"), "<mc,absorb,hg>"), (dict(boundary="reemit"), "<mc,reemit,hg>"),
+            (dict(scatter="iso"), "<mc,reflect,iso>"), (dict(order="gray", h=1.0), "<gray,reflect,hg>"),
+            (dict(boundary="absorb", n_depth_bins=8), "<mc,absorb,hg,depth>"),
+            (dict(order="gray", h=1.0, boundary="reemit", scatter="iso", n_depth_bins=4), "<gray,reemit,iso,depth>"),
+            (dict(abs_only=1), "<mc,reflect,hg,abs_only>"), (dict(abs_only=1, n_depth_bins=8), "<mc,reflect,hg,depth,abs_only>"),
+            (dict(geometry="shell", shell_inner=1.0), "<mc,reflect,hg,shell>"),
+            (dict(geometry="shell", shell_inner=1.0, boundary="reemit", scatter="draine_exact", n_depth_bins=8),
+             "<mc,reemit,draine_exact,depth,shell>"),
+            (dict(scatter="draine_exact", boundary="absorb"), "<mc,absorb,draine_exact>"),
+            (dict(escaped_mu=True), "<mc,reflect,hg,escaped_mu>"), (dict(order="gray", h=1.0, escaped_mu=True), "<gray,reflect,hg,escaped_mu>"),
+            (dict(order="gray", h=1.0, scatter="draine"), "<runtime>"), (dict(abs_only=1, boundary="absorb"), "<runtime>"),
+            (dict(geometry="shell", shell_inner=1.0, order="gray", h=1.0), "<runtime>"),
+            (dict(escaped_mu=True, n_depth_bins=4), "<runtime>"),
+            (dict(scatter="iso", rng="philox32x4"), "<runtime,philox32x4>"),
+            (dict(runtime_kernel=True), "<runtime>"), (dict(runtime_kernel=True, rng="philox32x4"), "<runtime,philox32x4>")]
     for kw, name in want:
         engine.run(rt.make_params(tau, 2000, **kw))
-        assert name in engine.last_kernel(), (kw, engine.last_kernel())
+        assert engine.last_kernel() == "walk_kernel" + name, (kw, engine.last_kernel())
 
 
 @pytest.mark.parametrize("order,boundary,scatter", [("mc", "reflect", "hg"), ("mc", "absorb", "hg"), ("mc", "reflect", "iso"),

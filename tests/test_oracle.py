@@ -158,19 +158,26 @@ def test_known_answer_two_stream(c_oracle):
 
 def test_known_answer_emergent_intensity(c_oracle):
     """tau=10 isotropic conservative slab with the re-emitting boundary: emergent intensity vs angle
-    (reference table intensity.dat / Numpy_random_walk.py:448-449)."""
-    n = 40000
+    (reference table intensity.dat / Numpy_random_walk.py:448-449).  The table is itself a Monte Carlo result: column 2
+    is the fraction of photons per cosine bin, column 3 its error, column 4 the intensity; compared within the combined
+    errors (2e5 photons here; tests/test_gpu_known_answers.py does it at 2e7)."""
+    import os
+    from conftest import GOLDEN
+    theta, frac, err, want = np.loadtxt(os.path.join(GOLDEN, "intensity.dat")).T
+    assert np.allclose(want, [1.224, 1.145, 1.065, 0.9885, 0.9117, 0.8375, 0.7508, 0.6769, 0.5786, 0.5135])  # Numpy_random_walk.py:449
+    n = 200000
     t = c_oracle.run(c_oracle.make_params(np.array([10.0]), n, order="gray", h=1.0, boundary="reemit", scatter="iso",
                                           monochromatic=1.0, rand_mu=1, n_mu_bins=10), [1.0], [0.0], [1.0], [1.0])
     counts = t.mu_hist[0, :10].astype(float)
     counts[9] += t.mu_hist[0, 10]
     mids = (np.arange(10) + 0.5) / 10
-    intensity = counts / (2 * n * mids) * 10  # Numpy_random_walk.py:446
-    thetas = np.array([18.2, 31.8, 41.4, 49.5, 56.6, 63.3, 69.5, 75.3, 81.4, 87.1])
-    want = np.array([1.224, 1.145, 1.065, 0.9885, 0.9117, 0.8375, 0.7508, 0.6769, 0.5786, 0.5135])
-    got = intensity[np.argsort(-mids)]  # table runs from small theta (mu near 1) to large
-    assert np.all(np.abs(np.degrees(np.arccos(np.sort(mids)[::-1])) - thetas) < 0.6)
-    np.testing.assert_allclose(got, want, rtol=0.06)
+    order = np.argsort(-mids)  # table runs from small theta (mu near 1) to large
+    assert np.all(np.abs(np.degrees(np.arccos(mids[order])) - theta) < 0.25)
+    got_frac = counts[order] / n
+    intensity = got_frac * 10 / (2 * mids[order])  # Numpy_random_walk.py:446
+    z = (got_frac - frac) / np.hypot(err, np.sqrt(got_frac / n))
+    assert np.max(np.abs(z)) < 4.0 and np.sum(z * z) < 29.6, z
+    np.testing.assert_allclose(intensity[:6], want[:6], rtol=0.03)
 
 
 def test_packed_stream_of_the_oracle(c_oracle):

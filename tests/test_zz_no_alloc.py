@@ -21,7 +21,7 @@ def _run(rt, eng, torch, tau, n_photons, static, n_depth_bins=0, **kw):
     slab = torch.full((na * ns * A.NSUM,), 7.0, dtype=torch.float64, device=dev)
     counts = torch.full((na * A.NCNT,), 7, dtype=torch.int64, device=dev)
     hist = torch.full((na * 11,), 7, dtype=torch.int64, device=dev)
-    depth = torch.full((max(2 * na * n_depth_bins, 1),), 7.0, dtype=torch.float64, device=dev)
+    depth = torch.full((max(na * ns * 2 * n_depth_bins, 1),), 7.0, dtype=torch.float64, device=dev)
     eng.run_device(prm, slab.data_ptr(), counts.data_ptr(), hist.data_ptr(), depth.data_ptr() if n_depth_bins else None,
                    torch.cuda.current_stream().cuda_stream, static=static)
     torch.cuda.synchronize()
@@ -40,13 +40,15 @@ def test_static_entry_point_matches_the_allocating_one(rt):
         for g, w in zip(got[:3], want[name][:3]):
             assert np.array_equal(g, w), name
     assert int(want["small"][1].reshape(-1, 10)[:, rt._abi.CNT_PHOTONS].sum()) == 3 * 5003
-    # other kernels and options go through the same work memory: generic kernel with depth bins, a rank's share
-    for kw in (dict(boundary="absorb", n_depth_bins=8), dict(rank=1, world=4), dict(order="gray", h=1.0)):
+    # other kernels and options go through the same work memory: depth bins (per-chunk rows of their own), the
+    # run-time kernel, a rank's share
+    for kw in (dict(boundary="absorb", n_depth_bins=8), dict(n_depth_bins=32, runtime_kernel=True), dict(rank=1, world=4),
+               dict(order="gray", h=1.0)):
         a = _run(rt, eng, torch, *small, static=False, **kw)
         b = _run(rt, eng, torch, *small, static=True, **kw)
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
         if kw.get("n_depth_bins"):
-            np.testing.assert_allclose(b[3], a[3], rtol=1e-12)   # floating-point atomics: equal to rounding
+            assert np.array_equal(a[3], b[3]) and np.any(a[3] != 0)
     eng.close()
 
 

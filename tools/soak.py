@@ -21,12 +21,12 @@ dev = torch.device("cuda", 0)
 buf = D.TallyBuffer(torch, len(cfg["tau_list"]), 8, 10, dev)
 stream = torch.cuda.current_stream().cuda_stream
 prm = rt.make_params(cfg["tau_list"], cfg["n_photons"], h=cfg["h"])
-eng.run_device(prm, *buf.pointers(), None, stream)
+eng.run_device(prm, *buf.pointers(), stream)
 first = buf.words.clone()
 bad = torch.zeros((), dtype=torch.int64, device=dev)
 t0 = time.perf_counter()
 for i in range(n_sweeps):
-    eng.run_device(prm, *buf.pointers(), None, stream, static=bool(i & 1))
+    eng.run_device(prm, *buf.pointers(), stream, static=bool(i & 1))
     bad += (buf.words != first).sum()
     if i % 200 == 199:
         print(f"{i + 1} sweeps, {int(bad.item())} words differ, {time.perf_counter() - t0:.1f} s", flush=True)

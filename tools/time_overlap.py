@@ -30,11 +30,11 @@ prm = rt.make_params(cfg["tau_list"], cfg["n_photons"], h=cfg["h"], rank=0, worl
 
 def run(n_streams, reps=40):
     for k in range(4):
-        engs[k % n_streams].run_device(prm, *bufs[k % n_streams].pointers(), None, streams[k % n_streams].cuda_stream)
+        engs[k % n_streams].run_device(prm, *bufs[k % n_streams].pointers(), streams[k % n_streams].cuda_stream)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(reps):
-        engs[k % n_streams].run_device(prm, *bufs[k % n_streams].pointers(), None, streams[k % n_streams].cuda_stream)
+        engs[k % n_streams].run_device(prm, *bufs[k % n_streams].pointers(), streams[k % n_streams].cuda_stream)
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / reps * 1e3
 

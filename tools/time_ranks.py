@@ -31,12 +31,12 @@ stream = torch.cuda.current_stream().cuda_stream
 def share(rank, world, reps=20):
     prm = rt.make_params(cfg["tau_list"], n, h=cfg["h"], rank=rank, world=world)
     for _ in range(3):
-        eng.run_device(prm, *buf.pointers(), None, stream)
+        eng.run_device(prm, *buf.pointers(), stream)
     torch.cuda.synchronize()
     eng.kernel_time(reset=True)
     t0 = time.perf_counter()
     for _ in range(reps):
-        eng.run_device(prm, *buf.pointers(), None, stream)
+        eng.run_device(prm, *buf.pointers(), stream)
     torch.cuda.synchronize()
     wall = (time.perf_counter() - t0) / reps * 1e3
     return eng.kernel_time()[0], wall
