@@ -177,6 +177,7 @@ def main():
     ap.add_argument("--photons", type=int, default=0, help="photons per atmosphere (0 = the workload's own): of the whole job "
                                                           "with --scaling strong, per GPU with --scaling weak")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="strong")
+    ap.add_argument("--slabs", type=int, default=8, help="fixed photon-id slabs per atmosphere (a multiple of --gpus; results depend on it, not on --gpus)")
     ap.add_argument("--cpu-photons", type=int, default=1000000)
     ap.add_argument("--cpu-procs", type=int, default=0, help="processes of the all-cores CPU baseline (0 = every core this process may use)")
     ap.add_argument("--no-cpu", action="store_true")
@@ -231,7 +232,7 @@ def main():
 
     A = rt._abi
     base_photons = args.photons or cfg["n_photons"]
-    n_slabs = 8
+    n_slabs = args.slabs
     if n_slabs % world:
         raise SystemExit(f"--gpus must divide the {n_slabs} photon-id slabs of an atmosphere")
     total_photons = base_photons * world if args.scaling == "weak" else base_photons
@@ -286,7 +287,9 @@ def main():
     if rank == 0:
         value = events / dt
         achieved = events_rank_last * FP64_OPS_PER_EVENT / (kernel_ms * 1e-3) / 1e12
-        traffic = committed_json("*_traffic.json", {"workload": cfg["name"], "photons_per_atmosphere": int(per_gpu)})
+        # counters cannot be collected inside this process: the figures of the latest committed counter passes of this
+        # kernel on this workload, each with the photon count it was taken at (traffic scaled to this launch's)
+        traffic = committed_json("*_traffic.json", {"workload": cfg["name"]})
         pmc = committed_json("*_pmc.json", {"workload": cfg["name"], "kernel": kernel_name})
         out = {
             "metric": "photon-scatter events/sec", "value": value, "unit": "events/s", "n_gpus": world,
@@ -306,7 +309,10 @@ def main():
             "photon_histories_per_s": float(last[:, A.CNT_PHOTONS].sum()) * args.steps / dt,
             "roofline": {"bound": "valu_fp64", "achieved": achieved, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_VECTOR_PEAK_TFLOPS,
-                         "traffic": None if traffic is None else float(traffic["bytes_per_launch"]),
+                         "traffic": None if traffic is None else float(traffic["bytes_per_launch"]) * per_gpu / traffic["photons_per_atmosphere"],
+                         "traffic_source": None if traffic is None else
+                         f"L2-to-fabric bytes of one launch at {traffic['photons_per_atmosphere']:.3g} photons per atmosphere "
+                         f"({traffic['bytes_per_launch']:.4g} B), scaled to {per_gpu:.3g}",
                          "kernel": kernel_name, "kernel_avg_ms": kernel_ms, "kernel_launches": launches,
                          "flop_per_event": FP64_OPS_PER_EVENT,
                          # issue side, from the committed counter pass of this kernel: share of the SIMDs' cycles that

@@ -14,15 +14,36 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 4000000
 eng = rt.Engine(0)
 eng.set_tables(cfg["wl"], cfg["g"], cfg["albedo"], cfg["scale"], cfg["pdf"])
 A = rt._abi
-for kw in (dict(), dict(boundary="absorb"), dict(boundary="reemit"), dict(scatter="iso"), dict(order="gray", h=1.0),
-           dict(n_depth_bins=32), dict(rand_mu=1), dict(abs_only=1), dict(scatter="draine_exact", alpha=0.3),
-           dict(geometry="shell", shell_inner=1.0), dict(geometry="shell", shell_inner=0.05, n_depth_bins=32),
-           dict(geometry="shell", shell_inner=1.0, scatter="draine_exact", alpha=0.3)):
+CASES = [dict(), dict(runtime_kernel=True), dict(rand_mu=1), dict(abs_only=1), dict(escaped_mu=True)]
+# every slab combination: loop order x boundary x {hg, iso} x depth bins
+for order in ("mc", "gray"):
+    for boundary in ("reflect", "absorb", "reemit"):
+        for scatter in ("hg", "iso"):
+            for nd in (0, 32):
+                kw = dict(boundary=boundary, scatter=scatter, n_depth_bins=nd)
+                if order == "gray":
+                    kw.update(order="gray", h=1.0)
+                if kw != dict(boundary="reflect", scatter="hg", n_depth_bins=0):
+                    CASES.append(kw)
+# the exact Draine law and the shell
+for boundary in ("reflect", "absorb", "reemit"):
+    for nd in (0, 32):
+        CASES.append(dict(scatter="draine_exact", alpha=0.3, boundary=boundary, n_depth_bins=nd))
+for scatter in ("hg", "draine_exact"):
+    for boundary in ("reflect", "absorb", "reemit"):
+        for nd in (0, 32):
+            CASES.append(dict(geometry="shell", shell_inner=1.0, scatter=scatter, alpha=0.3, boundary=boundary, n_depth_bins=nd))
+# what still has no instantiation of its own
+CASES += [dict(abs_only=1, boundary="absorb"), dict(escaped_mu=True, n_depth_bins=32), dict(order="gray", h=1.0, scatter="draine")]
+base_ms = None
+for kw in CASES:
     prm = rt.make_params(cfg["tau_list"], n, **({"h": cfg["h"]} | kw))
     eng.run(prm)
     eng.kernel_time(reset=True)
     res = eng.run(prm)
     ms, _ = eng.kernel_time()
     ev, fl = int(res.counts[:, A.CNT_SCATTER].sum()), int(res.counts[:, A.CNT_FLIGHTS].sum())
-    print(f"{str(kw):72s} {eng.last_kernel()[12:-1]:28s} {ms:8.3f} ms  flights {fl:.3e}  events {ev:.3e}  {fl / ms / 1e6:.1f} Gflights/s  {ev / ms / 1e6:.1f} Gevents/s")
+    rate = fl / ms / 1e6
+    base_ms = base_ms or rate
+    print(f"{str(kw):100s} {eng.last_kernel()[12:-1]:44s} {ms:8.3f} ms  flights {fl:.3e}  events {ev:.3e}  {rate:6.1f} Gflights/s ({rate / base_ms - 1:+.0%})  {ev / ms / 1e6:.1f} Gevents/s")
 eng.close()
