@@ -181,8 +181,9 @@ def main():
     ap.add_argument("--cpu-photons", type=int, default=1000000)
     ap.add_argument("--cpu-procs", type=int, default=0, help="processes of the all-cores CPU baseline (0 = every core this process may use)")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--rng", choices=["philox52", "philox32x4"], default="philox52",
-                    help="philox32x4 = the opt-in one-block-per-iteration stream with 32-bit uniforms (not the headline)")
+    ap.add_argument("--rng", choices=["philox52", "philox32x4", "philox40"], default="philox52",
+                    help="philox32x4 / philox40 = the opt-in one-block-per-iteration streams (32-bit uniforms; 24 | 40 | 40 | 24 "
+                         "bits); not the headline")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo stages the tallies through host memory; for rehearsing N > 1 on a box with fewer GPUs than ranks")
     args = ap.parse_args()
@@ -301,8 +302,10 @@ def main():
                                    f"{per_gpu:.3g} per GPU), {cfg['describe']}",
                        "photons_per_atmosphere_global": total_photons, "photon_histories_per_step": int(last[:, A.CNT_PHOTONS].sum()),
                        "flights_per_step": int(last[:, A.CNT_FLIGHTS].sum()), "events_per_step": events_last,
-                       "rng": "Philox4x32-10, " + ("52-bit uniforms, 2 blocks per loop iteration" if args.rng == "philox52"
-                                                   else "32-bit uniforms, 1 block per loop iteration (opt-in mode)"),
+                       "rng": "Philox4x32-10, " + {"philox52": "52-bit uniforms, 2 blocks per loop iteration",
+                                                   "philox32x4": "32-bit uniforms, 1 block per loop iteration (opt-in mode)",
+                                                   "philox40": "1 block per loop iteration cut as azimuth 24 | cosine 40 | step 40 | "
+                                                               "absorption 24 bits (opt-in mode)"}[args.rng],
                        "parallelism": f"photon-id slabs ({n_slabs} per atmosphere) over {world} GPU(s), "
                                       + ("no collective" if world == 1 else "1 all-reduce per step (one int64 buffer: slab sums "
                                                                            f"as bit patterns, counts, histogram; {buf.words.numel() * 8} bytes, {args.backend})")},

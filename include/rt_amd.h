@@ -131,9 +131,15 @@ enum {
  *   u = (w + 1/2) / 2^32: block k gives (azimuth, cosine) of the scattering BEFORE flight k in words 0-1 and
  *   (step, absorb) of flight k in words 2-3; block 0's words 0-1 (no scattering precedes the first flight)
  *   are the 52-bit emission draw.  Steps are then quantised to 2^-32 in xi (longest step 22.9), angles to
- *   2^-32 of a turn.  Not available with RT_SCATTER_DRAINE / RT_SCATTER_DRAINE_EXACT (their rejection loops need
+ *   2^-32 of a turn.
+ * RT_RNG_PHILOX40 (opt-in, as fast): the same one block per iteration with its 128 bits spent where the resolution
+ *   matters: azimuth 24 bits (top of word 0), cosine 40 bits (low 8 bits of word 0, word 1), step 40 bits (word 2,
+ *   top 8 bits of word 3), absorption 24 bits (low 24 bits of word 3), each uniform at the midpoint of its cell,
+ *   u = (k + 1/2) / 2^bits.  Steps are quantised to 2^-40 in xi (longest step 27.7 mean free paths, reached once in
+ *   1e12 flights), albedos effectively to 2^-24.  Emission as for RT_RNG_PHILOX32X4.
+ * Neither one-block stream is available with RT_SCATTER_DRAINE / RT_SCATTER_DRAINE_EXACT (their rejection loops need
  *   more than one block per iteration). */
-enum rt_rng_mode { RT_RNG_PHILOX52 = 0, RT_RNG_PHILOX32X4 = 1 };
+enum rt_rng_mode { RT_RNG_PHILOX52 = 0, RT_RNG_PHILOX32X4 = 1, RT_RNG_PHILOX40 = 2 };
 
 /* rt_params.flags */
 enum {
@@ -196,6 +202,8 @@ typedef struct rt_tallies {
                                order: bit for bit reproducible and independent of the number of GPUs, like `sums` */
     double* slab_sums;     /* [n_atm][n_slabs][RT_NSUM] per-slab partial sums (zero for slabs of other ranks);
                               summing the slab axis in index order gives `sums` bit for bit on any GPU count */
+    double* slab_depth;    /* [n_atm][n_slabs][2][n_depth_bins] the same for depth_momentum ([..][0][..]) and
+                              depth_energy ([..][1][..]) */
 } rt_tallies;
 
 /* Per-photon record written by rt_replay. */

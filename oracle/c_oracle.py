@@ -67,7 +67,7 @@ class Tallies:
         self.slab_sums = np.zeros((n_atm, n_slabs, abi.NSUM))
         self.c = abi.RtTallies(_dp(self.sums), self.counts.ctypes.data_as(abi.c_u64_p),
                                self.mu_hist.ctypes.data_as(abi.c_u64_p), _dp(self.depth_momentum),
-                               _dp(self.depth_energy), _dp(self.slab_sums))
+                               _dp(self.depth_energy), _dp(self.slab_sums), None)
 
 
 def trace_array(n):

@@ -68,7 +68,8 @@ def replay_reference(order, case):
         assert k == len(ids), (k, len(ids))
         j = st["ctr"][ids]
         st["ctr"][ids] = j + 1
-        return (philox.walk_uniform_packed if case.get("stream") == "philox32x4" else philox.walk_uniform)(ids, j, 0, seed)
+        draw = {"philox32x4": philox.walk_uniform_packed, "philox40": philox.walk_uniform_p40}.get(case.get("stream"), philox.walk_uniform)
+        return draw(ids, j, 0, seed)
 
     mod.np = _NumpyProxy(rand)
 
@@ -161,8 +162,8 @@ def make_case(name, order, n, tau, boundary, scatter, seed, abs_only=0, rand_mu0
         wl_t, g_t, alb_t, scale_t, pdf_t = (np.asarray(v, dtype=float) for v in table)
         ids = np.arange(n, dtype=np.uint64)
         # (the packed stream takes the emission draw from words 0-1 of walk block 0, which no scattering precedes)
-        u_wl, u_mu = philox.block_uniforms(ids, np.uint64(0 if stream == "philox32x4" else 0x80000000), 0, seed)
-        assert not (rand_mu0 and stream == "philox32x4")
+        u_wl, u_mu = philox.block_uniforms(ids, np.uint64(0 if stream != "philox52" else 0x80000000), 0, seed)
+        assert not (rand_mu0 and stream != "philox52")
         idx = c_oracle.sample_indices(pdf_t, u_wl)
         lam, g, alb, scale = wl_t[idx], g_t[idx], alb_t[idx], scale_t[idx]
         mu0 = u_mu if rand_mu0 else np.ones(n)
@@ -245,6 +246,17 @@ PACKED_CASES = [
 ]
 
 
+# ... and of the other one-block stream (24 | 40 | 40 | 24 bits)
+P40_CASES = [
+    make_case("mcq_reflect_hg_tau3", "mc", 3000, 3.0, "reflect", "hg", 701, uniform=(0.55, 0.63, 0.82, 1.3), stream="philox40"),
+    make_case("mcq_absorb_hg_tau2", "mc", 3000, 2.0, "absorb", "hg", 702, uniform=(0.25, 0.4, 0.85, 0.8), stream="philox40"),
+    make_case("mcq_reflect_iso_tau5", "mc", 3000, 5.0, "reflect", "iso", 703, uniform=(0.0912, 0.7, 0.6, 1.0), stream="philox40"),
+    make_case("grayq_reflect_hg_tau3", "gray", 3000, 3.0, "reflect", "hg", 704, gray_albedo=0.9, gray_g=0.5, stream="philox40"),
+    make_case("mcqt_reflect_hg_tau3", "mc", 4000, 3.0, "reflect", "hg", 705, table=_table("plain"), stream="philox40"),
+    make_case("mcqt_reflect_hg_tau10_smallg", "mc", 4000, 10.0, "reflect", "hg", 706, table=_table("small g"), stream="philox40"),
+]
+
+
 # Re-emission at the floor on a table: the re-emitted photon draws a new wavelength (and direction) from its next
 # emission block, so these cases have no fixed per-photon constants and only the production sweeps are compared with them.
 REEMIT_TABLE_CASES = [
@@ -321,6 +333,7 @@ def main():
               "fates", np.bincount(res["fate"], minlength=5))
     np.savez_compressed(os.path.join(GOLDEN, "walk_replay.npz"), **out)
     write_cases(PACKED_CASES, "walk_replay_packed.npz")
+    write_cases(P40_CASES, "walk_replay_philox40.npz")
     write_cases(REEMIT_TABLE_CASES, "walk_reemit_table.npz")
 
     out = {"names": np.array([c[0] for c in SEEDED_CASES])}

@@ -109,3 +109,26 @@ def walk_matrix_packed(n, max_draws, atm, seed, id_base=0):
     ids = (np.arange(n, dtype=np.uint64) + np.uint64(id_base))[:, None]
     j = np.arange(max_draws, dtype=np.uint64)[None, :]
     return np.ascontiguousarray(walk_uniform_packed(ids, j, atm, seed))
+
+
+# ---- the opt-in one-block stream with its 128 bits cut as 24 | 40 | 40 | 24 (RT_RNG_PHILOX40) ----
+def walk_uniform_p40(photon_id, j, atm, seed):
+    """Draw j of a photon's walk (step, absorb, azimuth, cosine, step, ...) under RT_RNG_PHILOX40: the block and word
+    pair of walk_uniform_packed, cut as azimuth 24 bits (top of word 0), cosine 40 (low 8 bits of word 0, word 1),
+    step 40 (word 2, top 8 bits of word 3), absorb 24 (low 24 bits of word 3); u = (k + 1/2) / 2**bits."""
+    j = np.asarray(j, dtype=np.uint64)
+    k, r = j >> np.uint64(2), j & np.uint64(3)
+    block = k + (r >= 2).astype(np.uint64)
+    w = [x & MASK32 for x in block_words(photon_id, block, atm, seed)]
+    step = ((w[2] << np.uint64(8)) | (w[3] >> np.uint64(24))).astype(np.float64)
+    absorb = (w[3] & np.uint64(0xFFFFFF)).astype(np.float64)
+    azimuth = (w[0] >> np.uint64(8)).astype(np.float64)
+    cosine = (((w[0] & np.uint64(0xFF)) << np.uint64(32)) | w[1]).astype(np.float64)
+    return np.where(r == 0, (step + 0.5) / 2.0 ** 40, np.where(r == 1, (absorb + 0.5) / 2.0 ** 24,
+                    np.where(r == 2, (azimuth + 0.5) / 2.0 ** 24, (cosine + 0.5) / 2.0 ** 40)))
+
+
+def walk_matrix_p40(n, max_draws, atm, seed, id_base=0):
+    ids = (np.arange(n, dtype=np.uint64) + np.uint64(id_base))[:, None]
+    j = np.arange(max_draws, dtype=np.uint64)[None, :]
+    return np.ascontiguousarray(walk_uniform_p40(ids, j, atm, seed))

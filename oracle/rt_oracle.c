@@ -60,6 +60,15 @@ static double u52(uint32_t a, uint32_t b) {
 
 /* RT_RNG_PHILOX32X4: one word per uniform, (w + 1/2) / 2^32 */
 static double u32mid(uint32_t w) { return ((double)w + 0.5) / 4294967296.0; }
+/* RT_RNG_PHILOX40: word r of a block (0 azimuth, 1 cosine, 2 step, 3 absorb) cut as 24 | 40 | 40 | 24 bits, midpoints */
+static double u40cut(const uint32_t w[4], uint32_t r) {
+    switch (r) {
+        case 0: return ((double)(w[0] >> 8) + 0.5) / 16777216.0;
+        case 1: return ((double)(((uint64_t)(w[0] & 0xFFu) << 32) | w[1]) + 0.5) / 1099511627776.0;
+        case 2: return ((double)(((uint64_t)w[2] << 8) | (w[3] >> 24)) + 0.5) / 1099511627776.0;
+        default: return ((double)(w[3] & 0xFFFFFFu) + 0.5) / 16777216.0;
+    }
+}
 
 static void block_words(uint64_t id, uint32_t block, uint32_t atm, uint64_t seed, uint32_t w[4]) {
     uint32_t ctr[4] = {(uint32_t)id, (uint32_t)(id >> 32), block, atm};
@@ -163,7 +172,7 @@ typedef struct {
     double ua, ub;
     /* RT_RNG_PHILOX32X4: walk draw j (0 step, 1 absorb, 2 azimuth, 3 cosine, 4 step, ...) is word (j + 2) & 3 of
      * block (j + 2) >> 2 -- words 0, 1 of block 0 belong to the emission */
-    int packed;
+    int packed; /* 0, RT_RNG_PHILOX32X4 or RT_RNG_PHILOX40 */
     uint32_t words[4];
 } stream_t;
 
@@ -176,7 +185,7 @@ static int draw(stream_t* s, double* u) {
             s->cur_block = block;
             s->have_block = 1;
         }
-        *u = u32mid(s->words[((uint32_t)j + 2u) & 3u]);
+        *u = s->packed == RT_RNG_PHILOX40 ? u40cut(s->words, ((uint32_t)j + 2u) & 3u) : u32mid(s->words[((uint32_t)j + 2u) & 3u]);
     } else if (s->use_philox) {
         uint32_t block = (uint32_t)j >> 1;
         if (!s->have_block || s->cur_block != block) {
@@ -518,12 +527,12 @@ int ora_run(const rt_params* p, int32_t n_tables, int32_t n_wl, const double* wl
                     s.seed = p->seed;
                     s.atm = (uint32_t)atm;
                     consts_t c;
-                    if (p->rng_mode == RT_RNG_PHILOX32X4) {
+                    if (p->rng_mode != RT_RNG_PHILOX52) {
                         /* wavelength from words 0, 1 of walk block 0 (52 bits); the direction draw, if any, is the
                          * second uniform of emission block 0, as in the default mode */
                         uint32_t w[4];
                         double ua, ub;
-                        s.packed = 1;
+                        s.packed = p->rng_mode;
                         block_words(s.id, 0u, s.atm, s.seed, w);
                         block_uniforms(s.id, EMIT_BLOCK, s.atm, s.seed, &ua, &ub);
                         s.n_emit = 1;

@@ -17,7 +17,7 @@ BOUNDARY = {"reflect": 0, "absorb": 1, "reemit": 2}
 SCATTER = {"hg": 0, "iso": 1, "draine": 2, "draine_exact": 3}
 GEOMETRY = {"slab": 0, "shell": 1}
 ORDER = {"mc": 0, "gray": 1}
-RNG = {"philox52": 0, "philox32x4": 1}
+RNG = {"philox52": 0, "philox32x4": 1, "philox40": 2}
 FLAG_RUNTIME_KERNEL = 1
 
 FATE_ESCAPED, FATE_ESCAPED_UNCOUNTED, FATE_ABSORBED, FATE_BOUNDARY, FATE_GUARD = 1, 2, 3, 4, 5
@@ -52,6 +52,7 @@ class RtTallies(C.Structure):
     _fields_ = [
         ("sums", c_double_p), ("counts", c_u64_p), ("mu_hist", c_u64_p),
         ("depth_momentum", c_double_p), ("depth_energy", c_double_p), ("slab_sums", c_double_p),
+        ("slab_depth", c_double_p),
     ]
 
 

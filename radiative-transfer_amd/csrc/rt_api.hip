@@ -140,10 +140,10 @@ int check_common(const rt_params* p) {
         return fail(RT_ERR_INVALID,
                     "scatter='draine' is only available with the gray loop order (it is disabled in the "
                     "wavelength-dependent reference script)");
-    if (p->rng_mode != RT_RNG_PHILOX52 && p->rng_mode != RT_RNG_PHILOX32X4)
-        return fail(RT_ERR_INVALID, "rng_mode=%d is not RT_RNG_PHILOX52 / RT_RNG_PHILOX32X4", p->rng_mode);
-    if (p->rng_mode == RT_RNG_PHILOX32X4 && (p->scatter == RT_SCATTER_DRAINE || p->scatter == RT_SCATTER_DRAINE_EXACT))
-        return fail(RT_ERR_INVALID, "RT_RNG_PHILOX32X4 has one block per loop iteration; the Draine rejection loop needs more");
+    if (p->rng_mode != RT_RNG_PHILOX52 && p->rng_mode != RT_RNG_PHILOX32X4 && p->rng_mode != RT_RNG_PHILOX40)
+        return fail(RT_ERR_INVALID, "rng_mode=%d is not RT_RNG_PHILOX52 / RT_RNG_PHILOX32X4 / RT_RNG_PHILOX40", p->rng_mode);
+    if (p->rng_mode != RT_RNG_PHILOX52 && (p->scatter == RT_SCATTER_DRAINE || p->scatter == RT_SCATTER_DRAINE_EXACT))
+        return fail(RT_ERR_INVALID, "RT_RNG_PHILOX32X4 / RT_RNG_PHILOX40 have one block per loop iteration; the Draine rejection loop needs more");
     if (p->scatter == RT_SCATTER_DRAINE_EXACT && !(p->alpha >= 0.0 && p->alpha <= 1.0))
         return fail(RT_ERR_INVALID, "scatter='draine_exact' needs 0 <= alpha <= 1 (got %g)", p->alpha);
     if (p->geometry != RT_GEOM_SLAB && p->geometry != RT_GEOM_SHELL)
@@ -246,7 +246,7 @@ void drain_events(rt_ctx* ctx) {
 // Which instantiation of the walk kernel serves a sweep: the one with exactly the sweep's flags fixed at compile time
 // where there is one, else the kernel that reads every flag at run time.
 int pick_variant(const rt_params* p, const rt::Cfg& cfg) {
-    const int runtime = p->rng_mode == RT_RNG_PHILOX32X4 ? rt::kWalkRuntimePacked : rt::kWalkRuntime;
+    const int runtime = rt::kWalkRuntime + p->rng_mode;  // one run-time kernel per random stream
     if (p->flags & RT_FLAG_RUNTIME_KERNEL) return runtime;
     rt::WalkKey k;
     k.order = p->loop_order;
@@ -738,7 +738,7 @@ int rt_run(rt_ctx* ctx, const rt_params* p, rt_tallies* out) {
     if (out->mu_hist)
         RT_HIP(hipMemcpyAsync(out->mu_hist, ctx->d_mu_hist.p, sizeof(uint64_t) * na * nmu, hipMemcpyDeviceToHost,
                               ctx->stream));
-    std::vector<double> slab_depth(nd && (out->depth_momentum || out->depth_energy) ? na * n_slabs * 2 * nd : 0);
+    std::vector<double> slab_depth(nd && (out->depth_momentum || out->depth_energy || out->slab_depth) ? na * n_slabs * 2 * nd : 0);
     if (!slab_depth.empty())
         RT_HIP(hipMemcpyAsync(slab_depth.data(), ctx->d_depth.p, sizeof(double) * slab_depth.size(), hipMemcpyDeviceToHost,
                               ctx->stream));
@@ -754,6 +754,7 @@ int rt_run(rt_ctx* ctx, const rt_params* p, rt_tallies* out) {
                 out->sums[a * RT_NSUM + k] = s;
             }
     }
+    if (!slab_depth.empty() && out->slab_depth) memcpy(out->slab_depth, slab_depth.data(), sizeof(double) * slab_depth.size());
     if (!slab_depth.empty()) {  // the slab axis summed in index order, like the sums: the same bits on any number of GPUs
         for (size_t a = 0; a < na; ++a)
             for (size_t k = 0; k < 2 * nd; ++k) {

@@ -80,6 +80,34 @@ __device__ __forceinline__ double m52(uint32_t a, uint32_t b) {
 // Uniform in (0,1) from one word: (w + 1/2) / 2^32, exact in fp64 (RT_RNG_PHILOX32X4).
 __device__ __forceinline__ double u32mid(uint32_t w) { return fma((double)w, 0x1p-32, 0x1p-33); }
 
+// RT_RNG_PHILOX40: the four uniforms of a loop iteration cut from ONE block as 24 | 40 | 40 | 24 bits, each at the
+// midpoint of its cell (never 0 or 1) and exact in fp64:
+//   azimuth (w0 >> 8 + 1/2) / 2^24,  cosine ((w0 & 255) 2^32 + w1 + 1/2) / 2^40,
+//   step    (w2 2^8 + (w3 >> 24) + 1/2) / 2^40,  absorption ((w3 & 0xffffff) + 1/2) / 2^24.
+// The 40-bit ones fill the fraction of a double in [1, 2) (two bit operations, a funnel shift, a subtraction); the
+// 24-bit ones go through an integer conversion.
+__device__ __forceinline__ double u40_step(uint32_t w2, uint32_t w3) {
+    const uint32_t hi = __builtin_amdgcn_alignbit(0x3FFu, w2, 12);                               // 0x3FF00000 | (w2 >> 12)
+    const uint32_t lo = __builtin_amdgcn_alignbit(w2, (w3 & 0xFF000000u) | 0x00800000u, 12);     // w2 << 20 | (w3 >> 24) << 12 | 1 << 11
+    return __hiloint2double((int)hi, (int)lo) - 1.0;
+}
+__device__ __forceinline__ double u40_cosine(uint32_t w0, uint32_t w1) {
+    const uint32_t hi = __builtin_amdgcn_alignbit((w0 & 0xFFu) | 0x3FF00u, w1, 20);              // 0x3FF00000 | (w0 & 255) << 12 | w1 >> 20
+    const uint32_t lo = (w1 << 12) | 0x800u;
+    return __hiloint2double((int)hi, (int)lo) - 1.0;
+}
+__device__ __forceinline__ double u24_azimuth(uint32_t w0) { return (double)((w0 & 0xFFFFFF00u) | 0x80u) * 0x1p-32; }
+__device__ __forceinline__ double u24_absorb(uint32_t w3) { return (double)((w3 << 8) | 0x80u) * 0x1p-32; }
+
+// How the one-block streams cut a block: (azimuth, cosine) of the scattering before a flight, (step, absorb) of the flight.
+template <int RNG>
+struct BlockCut {
+    static __device__ __forceinline__ double azimuth(const PhiloxOut& o) { return RNG == RT_RNG_PHILOX40 ? u24_azimuth(o.w0) : u32mid(o.w0); }
+    static __device__ __forceinline__ double cosine(const PhiloxOut& o) { return RNG == RT_RNG_PHILOX40 ? u40_cosine(o.w0, o.w1) : u32mid(o.w1); }
+    static __device__ __forceinline__ double step(const PhiloxOut& o) { return RNG == RT_RNG_PHILOX40 ? u40_step(o.w2, o.w3) : u32mid(o.w2); }
+    static __device__ __forceinline__ double absorb(const PhiloxOut& o) { return RNG == RT_RNG_PHILOX40 ? u24_absorb(o.w3) : u32mid(o.w3); }
+};
+
 struct TableRec {  // one wavelength: what CreatePhotons copies into a photon row (MC code.py:403-408), with the
                    // quotient GetZMomentum forms on every call, 1/lambda (MC code.py:367), taken once on the
                    // host (IEEE division, as NumPy's).  32 bytes: two 16-byte loads, and a record never

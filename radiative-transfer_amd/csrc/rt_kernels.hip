@@ -110,8 +110,8 @@ __global__ __launch_bounds__(256) void emission_kernel(const Cfg cfg, const int 
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const unsigned long long gid = first_id + (unsigned long long)i + cfg.id_base;
-    // the one-block stream takes the emission draw from words 0-1 of walk block 0, the direction from the emission block
-    const uint32_t block = rng_mode == RT_RNG_PHILOX32X4 ? 0u : kEmitBlock;
+    // the one-block streams take the emission draw from words 0-1 of walk block 0, the direction from the emission block
+    const uint32_t block = rng_mode != RT_RNG_PHILOX52 ? 0u : kEmitBlock;
     const PhiloxOut o = philox4x32_10((uint32_t)gid, (uint32_t)(gid >> 32), block, atm, cfg.k0, cfg.k1);
     out_index[i] = sample_index(cfg, u52(o.w0, o.w1)) - cfg.table_base;
     if (out_mu0) {
@@ -308,7 +308,7 @@ size_t walk_lds_bytes(int n_mu_bins, int n_depth_bins) {
 static const std::vector<WalkVariantInfo>& walk_variants() {
     static const std::vector<WalkVariantInfo> all = [] {
         std::vector<WalkVariantInfo> v;
-        register_walk_base(v);  // variants 0 and 1: the run-time kernels
+        register_walk_base(v);  // variants 0 to 2: the run-time kernels
         register_walk_slab_mc(v);
         register_walk_slab_gray(v);
         register_walk_shell(v);

@@ -54,7 +54,7 @@ constexpr int kWalkBlock = 256;
 size_t walk_lds_bytes(int n_mu_bins, int n_depth_bins);
 constexpr size_t kWalkLdsLimit = 64 * 1024;
 // The walk kernel's instantiations (rt_walk.hpp): which run flags are compile-time constants (see Fixed<> in
-// rt_device.hpp).  Variant 0 and 1 are the kernels that read every flag at run time (52-bit and one-block stream);
+// rt_device.hpp).  Variants 0 to 2 are the kernels that read every flag at run time (one per random stream);
 // the others are found by their key.
 typedef void (*WalkKernel)(const Cfg, const Sweep, unsigned int*, double*, unsigned long long*, unsigned long long*, double*);
 struct WalkVariantInfo {
@@ -64,7 +64,7 @@ struct WalkVariantInfo {
     WalkKernel fn;
     char name[112];
 };
-constexpr int kWalkRuntime = 0, kWalkRuntimePacked = 1;
+constexpr int kWalkRuntime = 0;  // + rng_mode: variants 0, 1, 2 are the run-time kernels of the three random streams
 int walk_variant_count();
 const WalkVariantInfo& walk_variant(int v);
 // the instantiation with exactly these flags fixed, or -1 (the sweep then runs a run-time kernel)

@@ -227,7 +227,7 @@ __device__ __forceinline__ void store_chunk_wave(const AccWave& acc, const unsig
 //                 (RT_ORDER_MC, reflecting boundary, Henyey-Greenstein, no depth bins, slab).
 //   V = Runtime   every flag read from cfg.
 // Both give the same photon histories as one fly() + scatter() per photon per iteration (flight()).
-//   RNG           RT_RNG_PHILOX52 (two blocks per iteration) or RT_RNG_PHILOX32X4 (one).
+//   RNG           RT_RNG_PHILOX52 (two blocks per iteration), RT_RNG_PHILOX32X4 or RT_RNG_PHILOX40 (one).
 //   PLAIN (with a Fixed V) also fixes the reference's defaults rand_mu = 0 and monochromatic = 0 at compile time: the
 //                 selects they cost per emission, and the scalar registers their operands occupy, go away.
 template <class V, int RNG, bool PLAIN>
@@ -239,7 +239,8 @@ __global__ __launch_bounds__(kWalkBlock) void walk_kernel(const Cfg cfg0, const 
                                                            double* __restrict__ d_chunk_depth) {
     // d_counts [n_copies][n_atm][RT_NCNT], d_mu_hist [n_copies][n_atm][n_mu_bins + 1], d_chunk_depth [slot][2][nd]
     extern __shared__ __align__(16) unsigned char lds_raw[];
-    constexpr bool PACKED = RNG == RT_RNG_PHILOX32X4;
+    constexpr bool PACKED = RNG != RT_RNG_PHILOX52;  // the one-block streams
+    typedef BlockCut<RNG> Cut;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int nmu = cfg0.n_mu_bins + 1;
@@ -365,8 +366,8 @@ __global__ __launch_bounds__(kWalkBlock) void walk_kernel(const Cfg cfg0, const 
                 constexpr bool MFORM = FAST && !PACKED;
                 // a photon that has flown k times has used 2k blocks -- unless its scattering law draws blocks of its own
                 constexpr bool BLOCK_GUARD = MFORM && !V::kRejection;
-                const double ua = MFORM ? m52(o.w0, o.w1) : ((!PACKED || fresh) ? u52(o.w0, o.w1) : u32mid(o.w0));
-                double ub = PACKED ? u32mid(o.w1) : u52(o.w2, o.w3);
+                const double ua = MFORM ? m52(o.w0, o.w1) : ((!PACKED || fresh) ? u52(o.w0, o.w1) : Cut::azimuth(o));
+                double ub = PACKED ? Cut::cosine(o) : u52(o.w2, o.w3);
                 // alias entry of the new photons' bucket, requested now; scattering lanes read entry 0 (broadcast)
                 const double xb = MFORM ? fma(ua, (double)cfg.n_wl, -(double)cfg.n_wl) : ua * (double)cfg.n_wl;
                 int bucket = (int)xb;
@@ -391,8 +392,8 @@ __global__ __launch_bounds__(kWalkBlock) void walk_kernel(const Cfg cfg0, const 
                 double u_step, u_abs;
                 if (PACKED) {
                     if (fresh) ++src.blk;
-                    u_step = u32mid(o.w2);
-                    u_abs = u32mid(o.w3);
+                    u_step = Cut::step(o);
+                    u_abs = Cut::absorb(o);
                     if (!PLAIN && cfg.rand_mu && fresh) {  // the direction draw of a new photon: second uniform of emission block 0
                         const PhiloxOut e = philox4x32_10(src.id_lo, src.id_hi, kEmitBlock, src.atm, src.k0, src.k1);
                         ub = u52(e.w2, e.w3);
@@ -490,6 +491,7 @@ inline void walk_variant_name(const WalkKey& k, bool fixed, char* out, size_t n)
         add(k.emu, "escaped_mu");
     }
     add(k.rng == RT_RNG_PHILOX32X4, "philox32x4");
+    add(k.rng == RT_RNG_PHILOX40, "philox40");
     add(k.plain, "plain");
     if (at > 0 && (size_t)at < n) snprintf(out + at, n - (size_t)at, ">");
 }

@@ -65,13 +65,8 @@ def result_from_arrays(slab_sums, counts, mu_hist, depth, n_atm, n_mu_bins, n_de
     res.slab_sums[...] = np.asarray(slab_sums, dtype=np.float64).reshape(n_atm, n_slabs, abi.NSUM)
     res.counts[...] = np.asarray(counts).reshape(n_atm, abi.NCNT).astype(np.uint64)
     res.mu_hist[...] = np.asarray(mu_hist).reshape(n_atm, n_mu_bins + 1).astype(np.uint64)
-    if n_depth_bins:  # [n_atm][n_slabs][2][n_depth_bins]: the slab axis added in index order, like the sums
-        d = np.asarray(depth, dtype=np.float64).reshape(n_atm, n_slabs, 2, n_depth_bins)
-        tot = np.zeros((n_atm, 2, n_depth_bins))
-        for s in range(n_slabs):
-            tot += d[:, s]
-        res.depth_momentum[...] = tot[:, 0]
-        res.depth_energy[...] = tot[:, 1]
+    if n_depth_bins:
+        res.slab_depth[...] = np.asarray(depth, dtype=np.float64).reshape(n_atm, n_slabs, 2, n_depth_bins)
     res.finalize_from_slabs()
     return res
 

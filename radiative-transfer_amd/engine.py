@@ -36,9 +36,10 @@ class SweepResult:
         self.depth_momentum = np.zeros((n_atm, max(n_depth_bins, 1)))
         self.depth_energy = np.zeros((n_atm, max(n_depth_bins, 1)))
         self.slab_sums = np.zeros((n_atm, n_slabs, abi.NSUM))
+        self.slab_depth = np.zeros((n_atm, n_slabs, 2, max(n_depth_bins, 1)))
         self.n_depth_bins = n_depth_bins
         self._c = abi.RtTallies(_dp(self.sums), _u64p(self.counts), _u64p(self.mu_hist), _dp(self.depth_momentum),
-                                _dp(self.depth_energy), _dp(self.slab_sums))
+                                _dp(self.depth_energy), _dp(self.slab_sums), _dp(self.slab_depth) if n_depth_bins else None)
 
     # the reference's names (RunPhotons return values, MC code.py:779)
     @property
@@ -62,6 +63,11 @@ class SweepResult:
         self.sums[...] = 0.0
         for s in range(self.slab_sums.shape[1]):
             self.sums += self.slab_sums[:, s, :]
+        if self.n_depth_bins:
+            tot = np.zeros_like(self.slab_depth[:, 0])
+            for s in range(self.slab_depth.shape[1]):
+                tot += self.slab_depth[:, s]
+            self.depth_momentum[...], self.depth_energy[...] = tot[:, 0], tot[:, 1]
 
     def momentum_fraction(self):
         """(initial - escaped + boundary) / initial per atmosphere, runMC, MC code.py:1062."""
@@ -92,8 +98,9 @@ def make_params(tau, n_photons, *, boundary="reflect", scatter="hg", order="mc",
                 n_mu_bins=10, n_depth_bins=0, max_events=0, n_slabs=8, rank=0, world=1, seed=DEFAULT_SEED,
                 photon_id_base=0, monochromatic=0.0, alpha=0.3, h=H_PLANCK, rng="philox52", table_of_atm=None,
                 geometry="slab", shell_inner=0.0, escaped_mu=False, runtime_kernel=False):
-    """rng: "philox52" (default; 52-bit uniforms, two Philox blocks per loop iteration) or "philox32x4" (one
-    block per iteration, 32-bit uniforms; faster, see rt_rng_mode in include/rt_amd.h).
+    """rng: "philox52" (default; 52-bit uniforms, two Philox blocks per loop iteration), "philox32x4" (one
+    block per iteration, 32-bit uniforms; faster) or "philox40" (one block per iteration cut as 24 | 40 | 40 | 24 bits:
+    as fast, finer steps and cosines); see rt_rng_mode in include/rt_amd.h.
     geometry: "slab" (the reference's) or "shell", a uniform spherical shell whose inner radius is `shell_inner`
     thicknesses (see RT_GEOM_SHELL in include/rt_amd.h; use SweepResult.deposited_fraction() for its result).
     escaped_mu: True asks Engine.run for the escape cosine of every photon (SweepResult.escaped_mu); an integer is taken

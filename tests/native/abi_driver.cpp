@@ -60,7 +60,7 @@ struct Result {
         dmom.assign(a * (size_t)p.n_depth_bins + 1, -1.0);
         den.assign(a * (size_t)p.n_depth_bins + 1, -1.0);
         t = {sums.data(), counts.data(), hist.data(), p.n_depth_bins ? dmom.data() : nullptr,
-             p.n_depth_bins ? den.data() : nullptr, slab.data()};
+             p.n_depth_bins ? den.data() : nullptr, slab.data(), nullptr};
     }
     bool histories_end_once(int n_atm) const {
         for (int a = 0; a < n_atm; ++a) {

@@ -27,7 +27,7 @@ def test_struct_layout_matches_header(rt):
     A = rt._abi
     # the size word + 12 int32 + a reserved one, 2 uint64, 3 doubles, 2 pointers, 2 int32, 1 pointer, 1 double, 1 pointer
     assert ctypes.sizeof(A.RtParams) == 14 * 4 + 2 * 8 + 3 * 8 + 2 * 8 + 2 * 4 + 8 + 8 + 8
-    assert ctypes.sizeof(A.RtTallies) == 6 * 8
+    assert ctypes.sizeof(A.RtTallies) == 7 * 8
     assert ctypes.sizeof(A.RtPhotonTrace) == 32
     assert A.RtParams.struct_size.offset == 0 and A.RtParams.seed.offset == 56 and A.RtParams.tau_atm.offset == 96
 

@@ -46,6 +46,8 @@ def draw_case(k):
         kw["table_of_atm"] = rs.randint(0, 3, n_atm)
     mono = rs.rand() < 0.2
     runtime = rs.rand() < 0.3  # (drawn last: the cases keep the options they had before this one existed)
+    if rs.rand() < 0.5 and kw["rng"] == "philox32x4":
+        kw["rng"] = "philox40"  # the other one-block stream
     return kw, tau, n_photons, multi, mono, runtime
 
 

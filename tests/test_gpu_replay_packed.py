@@ -1,6 +1,7 @@
-"""The opt-in stream with one Philox block per loop iteration and 32-bit uniforms (rng="philox32x4") against the
-reference itself.  tests/golden/walk_replay_packed.npz holds what the UNMODIFIED reference RunPhotons returned on the
-uniforms that stream defines (oracle.philox.walk_uniform_packed; generator: oracle/make_golden.py): replayed through
+"""The opt-in streams with one Philox block per loop iteration -- 32-bit uniforms (rng="philox32x4") and the 24 | 40 |
+40 | 24-bit cut (rng="philox40") -- against the reference itself.  tests/golden/walk_replay_packed.npz and
+walk_replay_philox40.npz hold what the UNMODIFIED reference RunPhotons returned on the uniforms those streams define
+(oracle.philox.walk_uniform_packed / walk_uniform_p40; generator: oracle/make_golden.py): replayed through
 the replay kernel photon by photon, and -- the photons of every case carrying the constants the production sweep gives
 them -- through the PRODUCTION kernels of that stream, which must return the reference's own numbers."""
 import os
@@ -15,11 +16,14 @@ from conftest import GOLDEN
 pytestmark = pytest.mark.gpu
 RTOL = 1e-12
 
-G = np.load(os.path.join(GOLDEN, "walk_replay_packed.npz"))
-NAMES = [str(n) for n in G["names"]]
+FILES = {"philox32x4": np.load(os.path.join(GOLDEN, "walk_replay_packed.npz")),
+         "philox40": np.load(os.path.join(GOLDEN, "walk_replay_philox40.npz"))}
+MATRIX = {"philox32x4": philox.walk_matrix_packed, "philox40": philox.walk_matrix_p40}
+NAMES = [(rng, str(n)) for rng, G in FILES.items() for n in G["names"]]
 
 
-def case(name):
+def case(name, rng="philox32x4"):
+    G = FILES[rng]
     return {k.split("/", 1)[1]: G[k] for k in G.files if k.startswith(name + "/")}
 
 
@@ -40,11 +44,11 @@ def check_tallies(rt, res, c, n):
     assert np.array_equal(res.mu_hist[0], ref_hist)
 
 
-@pytest.mark.parametrize("name", NAMES)
-def test_replay_on_the_packed_uniforms_matches_reference(rt, engine, name):
-    c = case(name)
+@pytest.mark.parametrize("rng,name", NAMES)
+def test_replay_on_the_packed_uniforms_matches_reference(rt, engine, rng, name):
+    c = case(name, rng)
     n, order = int(c["n"]), str(c["order"])
-    xi = philox.walk_matrix_packed(n, int(c["ref_draws"].max()), 0, int(c["seed"]))
+    xi = MATRIX[rng](n, int(c["ref_draws"].max()), 0, int(c["seed"]))
     prm = rt.make_params(float(c["tau"]), n, boundary=str(c["boundary"]), scatter=str(c["scatter"]), order=order,
                          h=(1.0 if order == "gray" else rt.H_PLANCK), n_mu_bins=10)
     res, tr = engine.replay(prm, xi, c["lam"], c["g"], c["albedo"], c["scale"], c["mu0"])
@@ -54,25 +58,26 @@ def test_replay_on_the_packed_uniforms_matches_reference(rt, engine, name):
     check_tallies(rt, res, c, n)
 
 
-@pytest.mark.parametrize("name", NAMES)
-def test_production_sweep_of_the_packed_stream_matches_reference(rt, engine, name):
-    c = case(name)
+@pytest.mark.parametrize("rng,name", NAMES)
+def test_production_sweep_of_the_packed_stream_matches_reference(rt, engine, rng, name):
+    c = case(name, rng)
     n, order = int(c["n"]), str(c["order"])
     if "table_wl" in c:
         engine.set_tables(c["table_wl"], c["table_g"], c["table_albedo"], c["table_scale"], c["table_pdf"])
     else:
         engine.set_tables([float(c["lam"][0])], [float(c["g"][0])], [float(c["albedo"][0])], [float(c["scale"][0])])
     res = engine.run(rt.make_params(float(c["tau"]), n, boundary=str(c["boundary"]), scatter=str(c["scatter"]), order=order,
-                                    h=(1.0 if order == "gray" else rt.H_PLANCK), seed=int(c["seed"]), rng="philox32x4", n_mu_bins=10))
-    assert "philox32x4" in engine.last_kernel()  # a kernel of the packed stream
+                                    h=(1.0 if order == "gray" else rt.H_PLANCK), seed=int(c["seed"]), rng=rng, n_mu_bins=10))
+    assert rng in engine.last_kernel()  # a kernel of that stream
     check_tallies(rt, res, c, n)
 
 
-def test_both_packed_instantiations_are_covered(rt, engine):
+@pytest.mark.parametrize("rng,prefix", [("philox32x4", "mcp"), ("philox40", "mcq")])
+def test_both_packed_instantiations_are_covered(rt, engine, rng, prefix):
     seen = set()
-    for name in ("mcp_reflect_hg_tau3", "mcp_absorb_hg_tau2"):
-        c = case(name)
+    for name in (prefix + "_reflect_hg_tau3", prefix + "_absorb_hg_tau2"):
+        c = case(name, rng)
         engine.set_tables([float(c["lam"][0])], [float(c["g"][0])], [float(c["albedo"][0])], [float(c["scale"][0])])
-        engine.run(rt.make_params(float(c["tau"]), 100, boundary=str(c["boundary"]), rng="philox32x4"))
+        engine.run(rt.make_params(float(c["tau"]), 100, boundary=str(c["boundary"]), rng=rng))
         seen.add(engine.last_kernel())
-    assert seen == {"walk_kernel<mc,reflect,hg,philox32x4,plain>", "walk_kernel<runtime,philox32x4>"}, seen
+    assert seen == {f"walk_kernel<mc,reflect,hg,{rng},plain>", f"walk_kernel<runtime,{rng}>"}, seen

@@ -1,5 +1,5 @@
-"""The opt-in one-block-per-iteration stream (RT_RNG_PHILOX32X4): exact agreement with the CPU oracle on the
-same stream, statistical agreement with the default 52-bit stream, and the documented restriction."""
+"""The opt-in one-block-per-iteration streams (RT_RNG_PHILOX32X4, RT_RNG_PHILOX40): exact agreement with the CPU
+oracle on the same stream, statistical agreement with the default 52-bit stream, and the documented restriction."""
 import numpy as np
 import pytest
 
@@ -10,22 +10,24 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("kw", [dict(), dict(boundary="absorb", scatter="iso"), dict(boundary="reemit", rand_mu=1),
                                 dict(order="gray", h=1.0, n_depth_bins=8), dict(rand_mu=1), dict(abs_only=1)])
-def test_packed_stream_matches_oracle(rt, engine, c_oracle, kw):
+@pytest.mark.parametrize("rng", ["philox32x4", "philox40"])
+def test_packed_stream_matches_oracle(rt, engine, c_oracle, kw, rng):
     wl, g, alb, scale, pdf = small_table()
     engine.set_tables(wl, g, alb, scale, pdf)
     tau = np.array([1e-3, 0.3, 2.0, 20.0])
-    kw = dict(n_mu_bins=10, rng="philox32x4") | kw
+    kw = dict(n_mu_bins=10, rng=rng) | kw
     res = engine.run(rt.make_params(tau, 6000, **kw))
     ref = c_oracle.run(c_oracle.make_params(tau, 6000, **kw), wl, g, alb, scale, pdf)
     compare(res, ref, rt._abi, nd=kw.get("n_depth_bins", 0))
 
 
-def test_packed_and_default_streams_agree_statistically(rt, engine):
+@pytest.mark.parametrize("rng", ["philox32x4", "philox40"])
+def test_packed_and_default_streams_agree_statistically(rt, engine, rng):
     wl, g, alb, scale, pdf = small_table()
     engine.set_tables(wl, g, alb, scale, pdf)
     tau = np.logspace(-2, 1.5, 8)
     a = engine.run(rt.make_params(tau, 2000000))
-    b = engine.run(rt.make_params(tau, 2000000, rng="philox32x4"))
+    b = engine.run(rt.make_params(tau, 2000000, rng=rng))
     assert not np.array_equal(a.counts, b.counts)  # different streams ...
     z = (a.momentum_fraction() - b.momentum_fraction()) / np.hypot(a.momentum_fraction_sigma(), b.momentum_fraction_sigma())
     assert np.all(np.abs(z) < 4.5), z                # ... same physics
@@ -35,14 +37,15 @@ def test_packed_and_default_streams_agree_statistically(rt, engine):
     np.testing.assert_allclose(ra, rb, rtol=5e-3, atol=2e-4)
 
 
-def test_packed_stream_is_independent_of_gpu_count(rt, engine):
+@pytest.mark.parametrize("rng", ["philox32x4", "philox40"])
+def test_packed_stream_is_independent_of_gpu_count(rt, engine, rng):
     wl, g, alb, scale, pdf = small_table()
     engine.set_tables(wl, g, alb, scale, pdf)
     tau = np.array([0.2, 3.0])
-    base = engine.run(rt.make_params(tau, 50000, rng="philox32x4"))
+    base = engine.run(rt.make_params(tau, 50000, rng=rng))
     slab, counts = np.zeros_like(base.slab_sums), np.zeros_like(base.counts)
     for rank in range(4):
-        r = engine.run(rt.make_params(tau, 50000, rank=rank, world=4, rng="philox32x4"))
+        r = engine.run(rt.make_params(tau, 50000, rank=rank, world=4, rng=rng))
         slab += r.slab_sums
         counts += r.counts
     assert np.array_equal(slab, base.slab_sums) and np.array_equal(counts, base.counts)
@@ -52,5 +55,7 @@ def test_packed_stream_refuses_draine(rt, engine):
     engine.set_tables([1.0], [0.5], [0.9], [1.0])
     with pytest.raises(rt.RtError):
         engine.run(rt.make_params(1.0, 100, order="gray", h=1.0, scatter="draine", rng="philox32x4"))
+    with pytest.raises(rt.RtError):
+        engine.run(rt.make_params(1.0, 100, scatter="draine_exact", rng="philox40"))
     with pytest.raises(ValueError):
         rt.make_params(1.0, 100, rng="mt19937")

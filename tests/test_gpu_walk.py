@@ -109,32 +109,45 @@ def test_draine_with_g_and_alpha_zero_is_isotropic(rt, engine, c_oracle):
 
 
 def test_result_independent_of_gpu_count(rt, engine):
-    """Walking the slabs as 1, 2, 4 or 8 ranks gives bitwise the same tallies after the slab sum."""
+    """Walking the slabs as 1, 2, 4 or 8 ranks gives bitwise the same tallies after the slab sum -- the
+    depth-resolved deposition included (per chunk, per slab in chunk order, slabs in index order)."""
     wl, g, alb, scale, pdf = small_table()
     engine.set_tables(wl, g, alb, scale, pdf)
     tau = np.array([0.2, 3.0])
-    base = engine.run(rt.make_params(tau, 50000))
-    for world in (2, 4, 8):
-        slab = np.zeros_like(base.slab_sums)
-        counts = np.zeros_like(base.counts)
-        hist = np.zeros_like(base.mu_hist)
-        for rank in range(world):
-            r = engine.run(rt.make_params(tau, 50000, rank=rank, world=world))
-            slab += r.slab_sums  # what an all-reduce(sum) of disjoint non-zero entries does
-            counts += r.counts
-            hist += r.mu_hist
-        assert np.array_equal(slab, base.slab_sums)
-        assert np.array_equal(counts, base.counts)
-        assert np.array_equal(hist, base.mu_hist)
+    for kw in (dict(n_depth_bins=16), dict(n_depth_bins=40, boundary="reemit", runtime_kernel=True)):
+        base = engine.run(rt.make_params(tau, 50000, **kw))
+        assert np.any(base.depth_momentum != 0) and np.any(base.depth_energy != 0)
+        for world in (2, 4, 8):
+            slab = np.zeros_like(base.slab_sums)
+            depth = np.zeros_like(base.slab_depth)
+            counts = np.zeros_like(base.counts)
+            hist = np.zeros_like(base.mu_hist)
+            for rank in range(world):
+                r = engine.run(rt.make_params(tau, 50000, rank=rank, world=world, **kw))
+                slab += r.slab_sums  # what an all-reduce(sum) of disjoint non-zero entries does
+                depth += r.slab_depth
+                counts += r.counts
+                hist += r.mu_hist
+            assert np.array_equal(slab, base.slab_sums) and np.array_equal(depth, base.slab_depth)
+            assert np.array_equal(counts, base.counts)
+            assert np.array_equal(hist, base.mu_hist)
+            whole = rt.SweepResult(len(tau), 10, kw["n_depth_bins"], 8)
+            whole.slab_sums[...], whole.slab_depth[...] = slab, depth
+            whole.finalize_from_slabs()
+            assert np.array_equal(whole.sums, base.sums)
+            assert np.array_equal(whole.depth_momentum, base.depth_momentum) and np.array_equal(whole.depth_energy, base.depth_energy)
 
 
 def test_rerun_is_bitwise_reproducible(rt, engine):
     wl, g, alb, scale, pdf = small_table()
     engine.set_tables(wl, g, alb, scale, pdf)
-    prm = rt.make_params(np.array([1.0, 8.0]), 300000)
+    prm = rt.make_params(np.array([1.0, 8.0]), 300000, n_depth_bins=32)
     a = engine.run(prm)
-    b = engine.run(prm)
-    assert np.array_equal(a.sums, b.sums) and np.array_equal(a.counts, b.counts)
+    for _ in range(3):
+        b = engine.run(prm)
+        assert np.array_equal(a.sums, b.sums) and np.array_equal(a.counts, b.counts) and np.array_equal(a.mu_hist, b.mu_hist)
+        assert np.array_equal(a.depth_momentum, b.depth_momentum) and np.array_equal(a.depth_energy, b.depth_energy)
+        assert np.array_equal(a.slab_depth, b.slab_depth)
 
 
 def test_errors(rt, engine):
@@ -209,6 +222,8 @@ def test_which_kernel_serves_which_flags(rt, engine):
             (dict(geometry="shell", shell_inner=1.0, order="gray", h=1.0), "<runtime>"),
             (dict(escaped_mu=True, n_depth_bins=4), "<runtime>"),
             (dict(scatter="iso", rng="philox32x4"), "<runtime,philox32x4>"),
+            (dict(rng="philox40"), "<mc,reflect,hg,philox40,plain>"), (dict(rng="philox40", monochromatic=1.0), "<mc,reflect,hg,philox40>"),
+            (dict(rng="philox40", boundary="absorb"), "<runtime,philox40>"),
             (dict(runtime_kernel=True), "<runtime>"), (dict(runtime_kernel=True, rng="philox32x4"), "<runtime,philox32x4>")]
     for kw, name in want:
         engine.run(rt.make_params(tau, 2000, **kw))

@@ -180,26 +180,29 @@ def test_known_answer_emergent_intensity(c_oracle):
     np.testing.assert_allclose(intensity[:6], want[:6], rtol=0.03)
 
 
-def test_packed_stream_of_the_oracle(c_oracle):
-    """RT_RNG_PHILOX32X4 in the oracle: same physics as the default stream (statistically) on a small sweep."""
+@pytest.mark.parametrize("rng", ["philox32x4", "philox40"])
+def test_packed_stream_of_the_oracle(c_oracle, rng):
+    """The one-block streams in the oracle: same physics as the default stream (statistically) on a small sweep."""
     wl = np.array([0.5]); g = np.array([0.6]); alb = np.array([0.7]); sc = np.array([1.0])
     tau = np.array([0.1, 1.0, 5.0])
     a = c_oracle.run(c_oracle.make_params(tau, 300000), wl, g, alb, sc, None)
-    b = c_oracle.run(c_oracle.make_params(tau, 300000, rng="philox32x4"), wl, g, alb, sc, None)
+    b = c_oracle.run(c_oracle.make_params(tau, 300000, rng=rng), wl, g, alb, sc, None)
     assert not np.array_equal(a.counts, b.counts)
     fa = (a.sums[:, 0] - a.sums[:, 1] + a.sums[:, 2]) / a.sums[:, 0]
     fb = (b.sums[:, 0] - b.sums[:, 1] + b.sums[:, 2]) / b.sums[:, 0]
     np.testing.assert_allclose(fa, fb, rtol=0.03)
 
 
-PACKED = np.load(os.path.join(os.path.dirname(__file__), "golden", "walk_replay_packed.npz"))
+ONE_BLOCK = {"philox32x4": np.load(os.path.join(os.path.dirname(__file__), "golden", "walk_replay_packed.npz")),
+             "philox40": np.load(os.path.join(os.path.dirname(__file__), "golden", "walk_replay_philox40.npz"))}
 
 
-@pytest.mark.parametrize("name", [str(n) for n in PACKED["names"]])
-def test_c_oracle_packed_production_matches_reference(c_oracle, name):
-    """The one-block stream (rng='philox32x4') of the C restatement in PRODUCTION mode against the unmodified
-    reference run on that stream's uniforms (oracle/philox.walk_uniform_packed): the golden's photons carry the
-    constants the sweep gives them, so the sweep must return the reference's own numbers."""
+@pytest.mark.parametrize("rng,name", [(r, str(n)) for r, f in ONE_BLOCK.items() for n in f["names"]])
+def test_c_oracle_packed_production_matches_reference(c_oracle, rng, name):
+    """The one-block streams (rng='philox32x4', 'philox40') of the C restatement in PRODUCTION mode against the
+    unmodified reference run on those streams' uniforms (oracle/philox.walk_uniform_packed / walk_uniform_p40): the
+    golden's photons carry the constants the sweep gives them, so the sweep must return the reference's own numbers."""
+    PACKED = ONE_BLOCK[rng]
     c = {k.split("/", 1)[1]: PACKED[k] for k in PACKED.files if k.startswith(name + "/")}
     n, order = int(c["n"]), str(c["order"])
     if "table_wl" in c:
@@ -207,7 +210,7 @@ def test_c_oracle_packed_production_matches_reference(c_oracle, name):
     else:
         tab = ([float(c["lam"][0])], [float(c["g"][0])], [float(c["albedo"][0])], [float(c["scale"][0])])
     prm = c_oracle.make_params(float(c["tau"]), n, boundary=str(c["boundary"]), scatter=str(c["scatter"]), order=order,
-                               h=(1.0 if order == "gray" else 6.6261e-27), seed=int(c["seed"]), rng="philox32x4", n_mu_bins=10)
+                               h=(1.0 if order == "gray" else 6.6261e-27), seed=int(c["seed"]), rng=rng, n_mu_bins=10)
     res = c_oracle.run(prm, *tab)
     fates = np.bincount(c["ref_fate"], minlength=6)
     cnt = res.counts[0].astype(np.int64)

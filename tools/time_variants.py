@@ -35,9 +35,14 @@ for scatter in ("hg", "draine_exact"):
             CASES.append(dict(geometry="shell", shell_inner=1.0, scatter=scatter, alpha=0.3, boundary=boundary, n_depth_bins=nd))
 # what still has no instantiation of its own
 CASES += [dict(abs_only=1, boundary="absorb"), dict(escaped_mu=True, n_depth_bins=32), dict(order="gray", h=1.0, scatter="draine")]
+ONLY = sys.argv[2].split(";") if len(sys.argv) > 2 else None  # only these kernels, e.g. "mc,reflect,hg,depth;gray,reemit,hg"
 base_ms = None
 for kw in CASES:
     prm = rt.make_params(cfg["tau_list"], n, **({"h": cfg["h"]} | kw))
+    if ONLY and kw:
+        eng.run(rt.make_params(cfg["tau_list"][:1], 100, **({"h": cfg["h"]} | kw)))
+        if eng.last_kernel()[12:-1] not in ONLY:
+            continue
     eng.run(prm)
     eng.kernel_time(reset=True)
     res = eng.run(prm)
