@@ -194,6 +194,7 @@ struct Photon {
     double dep;  // RT_GEOM_SHELL: radial momentum this photon has deposited so far
     uint32_t iter;
     int32_t n_scatter;
+    int32_t kbin;  // depth bin of the position the last flight ended at (kernels with depth bins)
 };
 
 struct Acc {
@@ -513,6 +514,9 @@ __device__ __forceinline__ int fly_path(const Cfg& cfg, Photon& ph, double path,
     // Absorb
     if (bounded && avail < 2) return RT_FATE_GUARD;
     n_used += 1;
+    // the bin of this position, once for whichever tally follows here: the absorption below or the scattering the
+    // caller performs next (nothing moves the photon in between)
+    if (depth) ph.kbin = depth_bin<V::kFixed>(cfg, ph);
     const bool absorbed = V::abs_only(cfg) ? (u_abs > 0.0) : (u_abs > ph.albedo);
     if (absorbed) {
         const double pa = ph.mu * ph.wh;
@@ -520,9 +524,8 @@ __device__ __forceinline__ int fly_path(const Cfg& cfg, Photon& ph, double path,
         acc.add(RT_SUM_ABSORBED_ENERGY, ph.wh);
         if (shell) ph.dep += pa;
         if (depth) {
-            const int k = depth_bin<V::kFixed>(cfg, ph);
-            atomicAdd(&hist.depth_mom[k], pa);
-            atomicAdd(&hist.depth_en[k], ph.wh);
+            atomicAdd(&hist.depth_mom[ph.kbin], pa);
+            atomicAdd(&hist.depth_en[ph.kbin], ph.wh);
         }
         return RT_FATE_ABSORBED;
     }
@@ -627,7 +630,7 @@ __device__ __forceinline__ int scatter(const Cfg& cfg, Photon& ph, Src& src, dou
     const double dp = (mu_old - mu_new) * ph.wh;
     acc.add(RT_SUM_DUST_MOMENTUM, dp);
     if (shell) ph.dep += dp;
-    if (depth) atomicAdd(&hist.depth_mom[depth_bin<V::kFixed>(cfg, ph)], dp);
+    if (depth) atomicAdd(&hist.depth_mom[ph.kbin], dp);
     return 0;
 }
 
