@@ -230,8 +230,12 @@ __device__ __forceinline__ void store_chunk_wave(const AccWave& acc, const unsig
 //   RNG           RT_RNG_PHILOX52 (two blocks per iteration), RT_RNG_PHILOX32X4 or RT_RNG_PHILOX40 (one).
 //   PLAIN (with a Fixed V) also fixes the reference's defaults rand_mu = 0 and monochromatic = 0 at compile time: the
 //                 selects they cost per emission, and the scalar registers their operands occupy, go away.
+//
+// The lean kernels of the re-emitting boundary are held to 5 waves per SIMD (96 vector registers; their depth-bin forms
+// spill 3 to 5 dwords for it): the two dependent gathers of a re-emission sit in the middle of the flight with nothing
+// of the wave's own to run under them, so they are the kernels that gain from one more resident wave (+2 ... +5 %).
 template <class V, int RNG, bool PLAIN>
-__global__ __launch_bounds__(kWalkBlock) void walk_kernel(const Cfg cfg0, const Sweep sw,
+__global__ __launch_bounds__(kWalkBlock, (V::kFixed && V::kReemit) ? 5 : 1) void walk_kernel(const Cfg cfg0, const Sweep sw,
                                                            unsigned int* __restrict__ d_next,
                                                            double* __restrict__ d_chunk_sums,
                                                            unsigned long long* __restrict__ d_counts,

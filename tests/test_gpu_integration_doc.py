@@ -1,4 +1,4 @@
-"""INTEGRATION.md's raw ctypes snippet, run end to end on the GPU as a maintainer would paste it: same numbers as
+"""The integration guide's raw ctypes snippet, run end to end on the GPU as a maintainer would paste it: same numbers as
 the package's own host layer, and a struct typed from an older header is refused instead of being read past its end."""
 import ctypes as C
 import importlib

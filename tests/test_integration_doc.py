@@ -1,4 +1,4 @@
-"""INTEGRATION.md's hand-written ctypes binding is executed as it stands: its structs must have the size and the
+"""The integration guide's hand-written ctypes binding is executed as it stands: its structs must have the size and the
 field offsets of include/rt_amd.h (through the package's own mirror, which tests/test_abi.py compares with the header
 compiled by gcc), so a binding typed from the document cannot hand the library a struct of another layout."""
 import ctypes

@@ -3,7 +3,10 @@ sys.path.insert(0,'.')
 rt = importlib.import_module("radiative-transfer_amd"); w = importlib.import_module("radiative-transfer_amd.workloads")
 A = rt._abi
 cfg = w.mix_2e7()
-eng = rt.Engine(0); eng.set_tables(cfg["wl"], cfg["g"], cfg["albedo"], cfg["scale"], cfg["pdf"])
+t0 = time.perf_counter(); eng = rt.Engine(0); t1 = time.perf_counter()
+eng2 = rt.Engine(0); t2 = time.perf_counter(); eng2.close()
+print("rt_create: first context %.1f ms (loads the code object, asks the occupancy of every instantiation), second %.1f ms" % ((t1 - t0) * 1e3, (t2 - t1) * 1e3))
+t0 = time.perf_counter(); eng.set_tables(cfg["wl"], cfg["g"], cfg["albedo"], cfg["scale"], cfg["pdf"]); print("rt_set_tables (99 991 wavelengths): %.1f ms" % ((time.perf_counter() - t0) * 1e3))
 tau = cfg["tau_list"]; n_atm=len(tau)
 dev = torch.device("cuda",0)
 slab = torch.zeros(n_atm*8*A.NSUM, dtype=torch.float64, device=dev); counts = torch.zeros(n_atm*A.NCNT, dtype=torch.int64, device=dev); hist = torch.zeros(n_atm*11, dtype=torch.int64, device=dev)
