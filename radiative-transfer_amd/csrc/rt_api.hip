@@ -80,9 +80,8 @@ struct rt_ctx {
     int32_t n_wl = 0;
     int32_t n_tables = 0;
     std::vector<double> wl;
-    DevBuf<rt::TableRec> d_rec;
+    DevBuf<rt::TableRec> d_rec, d_rec_gray;  // weight = 1/lambda (MC loop order), = lambda (gray loop order)
     DevBuf<rt::AliasEntry> d_alias;
-    DevBuf<double> d_lam;
     DevBuf<rt::LogTableEntry> d_log_table;
     // sweep workspace
     DevBuf<unsigned char> d_work;  // plan + item prefix + queue counter + chunk partial sums (see WorkLayout)
@@ -175,9 +174,8 @@ rt::Cfg make_cfg(const rt_ctx* ctx, const rt_params* p) {
     c.k0 = (uint32_t)p->seed;
     c.k1 = (uint32_t)(p->seed >> 32);
     c.id_base = p->photon_id_base;
-    c.rec = ctx->d_rec.p;
+    c.rec = p->loop_order == RT_ORDER_GRAY ? ctx->d_rec_gray.p : ctx->d_rec.p;
     c.alias = ctx->d_alias.p;
-    c.lam = ctx->d_lam.p;
     c.n_wl = ctx->n_wl;
     c.mono_index = -1;
     c.log_table = ctx->d_log_table.p;
@@ -598,7 +596,7 @@ int rt_destroy(rt_ctx* ctx) {
     }
     ctx->d_rec.release();
     ctx->d_alias.release();
-    ctx->d_lam.release();
+    ctx->d_rec_gray.release();
     ctx->d_log_table.release();
     ctx->d_work.release();
     ctx->d_escaped_mu.release();
@@ -678,8 +676,9 @@ int rt_set_tables_multi(rt_ctx* ctx, int32_t n_tables, int32_t n_wl, const doubl
     RT_HIP(hipDeviceSynchronize());
     RT_HIP(hipMemcpy(ctx->d_rec.p, rec.data(), sizeof(rt::TableRec) * total_n, hipMemcpyHostToDevice));
     RT_HIP(hipMemcpy(ctx->d_alias.p, alias.data(), sizeof(rt::AliasEntry) * total_n, hipMemcpyHostToDevice));
-    RT_HIP(ctx->d_lam.reserve(n));
-    RT_HIP(hipMemcpy(ctx->d_lam.p, wl, sizeof(double) * n, hipMemcpyHostToDevice));
+    for (size_t k = 0; k < total_n; ++k) rec[k].weight = wl[k % n];  // the gray loop order's records
+    RT_HIP(ctx->d_rec_gray.reserve(total_n));
+    RT_HIP(hipMemcpy(ctx->d_rec_gray.p, rec.data(), sizeof(rt::TableRec) * total_n, hipMemcpyHostToDevice));
     ctx->n_wl = n_wl;
     ctx->n_tables = n_tables;
     ctx->wl.assign(wl, wl + n_wl);

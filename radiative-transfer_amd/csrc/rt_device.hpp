@@ -109,12 +109,13 @@ struct BlockCut {
 };
 
 struct TableRec {  // one wavelength: what CreatePhotons copies into a photon row (MC code.py:403-408), with the
-                   // quotient GetZMomentum forms on every call, 1/lambda (MC code.py:367), taken once on the
-                   // host (IEEE division, as NumPy's).  32 bytes: two 16-byte loads, and a record never
-                   // straddles a 128-byte cache line (a 48-byte record with 1/(2g) stored as well did one time
-                   // in four, and the extra misses cost more than the division does).  lambda itself, which only
-                   // the gray loop order weights by, lives in Cfg::lam.
-    double g, albedo, scale, inv_lam;
+                   // photon's momentum weight: the quotient GetZMomentum forms on every call, 1/lambda
+                   // (MC code.py:367), taken once on the host (IEEE division, as NumPy's) -- or lambda itself, which
+                   // the gray loop order weights by; the host keeps one record array per loop order and a sweep
+                   // reads the one of its order.  32 bytes: two 16-byte loads, and a record never straddles a
+                   // 128-byte cache line (a 48-byte record with 1/(2g) stored as well did one time in four, and
+                   // the extra misses cost more than the division does).
+    double g, albedo, scale, weight;
 };
 static_assert(sizeof(TableRec) == 32, "two 16-byte loads per record");
 
@@ -137,9 +138,8 @@ struct Cfg {
     uint32_t k0, k1;
     uint64_t id_base;
     // emission tables
-    const TableRec* rec;
+    const TableRec* rec;      // the record array of this sweep's loop order (TableRec::weight)
     const AliasEntry* alias;  // n_wl entries
-    const double* lam;        // n_wl wavelengths (shared by all tables); read in the gray loop order only
     int32_t n_wl, mono_index;
     int32_t table_base;  // first entry of the current atmosphere's table in rec / alias (several tables back to back)
     const LogTableEntry* log_table;  // kLogTableEntries entries in global memory (copied to LDS per workgroup)
@@ -342,12 +342,9 @@ __device__ __forceinline__ TableRec load_record(const Cfg& cfg, int i) {
     return {a.x, a.y, b.x, b.y};
 }
 
-// `local` is the record's index inside its table (the wavelength index).
 template <class V>
-__device__ __forceinline__ void set_constants(const Cfg& cfg, double tau, const TableRec& r, int local, double mu0,
-                                              Photon& ph) {
-    const double w = V::gray(cfg) ? cfg.lam[local] : r.inv_lam;
-    ph.wh = w * cfg.h;
+__device__ __forceinline__ void set_constants(const Cfg& cfg, double tau, const TableRec& r, double mu0, Photon& ph) {
+    ph.wh = r.weight * cfg.h;
     ph.g = r.g;
     ph.albedo = r.albedo;
     ph.zmax = tau * r.scale;
@@ -376,7 +373,7 @@ __device__ __forceinline__ void emit_from_table(const Cfg& cfg, double tau, Phil
         i = sample_index(cfg, ua);
     }
     const TableRec r = BUF ? load_record_buffer(cfg, i) : load_record(cfg, i);
-    set_constants<V>(cfg, tau, r, i - cfg.table_base, cfg.rand_mu ? ub : 1.0, ph);
+    set_constants<V>(cfg, tau, r, cfg.rand_mu ? ub : 1.0, ph);
 }
 
 // LEAN: the quotient by the unscaled division sequence (the IEEE quotient for the normal operands that occur: 0 <= z <= zmax)

@@ -386,7 +386,6 @@ __global__ __launch_bounds__(kWalkBlock, (V::kFixed && V::kReemit) ? 5 : 1) void
                 const double prob = __hiloint2double((int)raw.y, (int)raw.x);
                 int idx = (xb - (double)bucket) < prob ? bucket : (int)raw.z;
                 if (!PLAIN) idx = cfg.mono_index >= 0 ? cfg.mono_index : idx;
-                const int local = fresh ? idx : 0;
                 idx = fresh ? cfg.table_base + idx : 0;
                 const TableRec rec = FAST ? load_record_buffer(cfg, idx) : load_record(cfg, idx);
                 // the iteration guard: ph.iter flights so far.  In the production kernel the block counter serves and
@@ -406,7 +405,7 @@ __global__ __launch_bounds__(kWalkBlock, (V::kFixed && V::kReemit) ? 5 : 1) void
                     src.pair(u_step, u_abs);
                 }
                 if (fresh) {
-                    set_constants<V>(cfg, tau, rec, local, (!PLAIN && cfg.rand_mu) ? ub : 1.0, ph);
+                    set_constants<V>(cfg, tau, rec, (!PLAIN && cfg.rand_mu) ? ub : 1.0, ph);
                     start_photon(ph, acc);
                     alive = true;
                 }

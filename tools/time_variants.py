@@ -1,4 +1,5 @@
-"""Kernel time of the headline sweep under other flag combinations (which kernel serves them and how fast)."""
+"""Kernel time of the headline sweep under other flag combinations (which kernel serves them and how fast): median of
+7 launches each on a warmed-up GPU, relative to the first case (the production configuration)."""
 import importlib
 import os
 import sys
@@ -7,10 +8,12 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+from _warm import median_kernel_ms, warm  # noqa: E402  (tools/ is the script's own directory)
+
 rt = importlib.import_module("radiative-transfer_amd")
 workloads = importlib.import_module("radiative-transfer_amd.workloads")
 cfg = workloads.WORKLOADS["mix_2e7"]()
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 4000000
+n = int(sys.argv[1]) if len(sys.argv) > 1 else cfg["n_photons"]
 eng = rt.Engine(0)
 eng.set_tables(cfg["wl"], cfg["g"], cfg["albedo"], cfg["scale"], cfg["pdf"])
 A = rt._abi
@@ -37,6 +40,7 @@ for scatter in ("hg", "draine_exact"):
 CASES += [dict(abs_only=1, boundary="absorb"), dict(escaped_mu=True, n_depth_bins=32), dict(order="gray", h=1.0, scatter="draine")]
 ONLY = sys.argv[2].split(";") if len(sys.argv) > 2 else None  # only these kernels, e.g. "mc,reflect,hg,depth;gray,reemit,hg"
 base_ms = None
+warm(rt, eng, cfg)
 for kw in CASES:
     prm = rt.make_params(cfg["tau_list"], n, **({"h": cfg["h"]} | kw))
     if ONLY and kw:
@@ -44,9 +48,7 @@ for kw in CASES:
         if eng.last_kernel()[12:-1] not in ONLY:
             continue
     eng.run(prm)
-    eng.kernel_time(reset=True)
-    res = eng.run(prm)
-    ms, _ = eng.kernel_time()
+    ms, res = median_kernel_ms(eng, prm)
     ev, fl = int(res.counts[:, A.CNT_SCATTER].sum()), int(res.counts[:, A.CNT_FLIGHTS].sum())
     rate = fl / ms / 1e6
     base_ms = base_ms or rate
