@@ -21,6 +21,7 @@
 namespace rt {
 
 constexpr int kWavesPerBlock = kWalkBlock / 64;
+constexpr int kHeldWaves = 5;  // waves per SIMD the lean instantiations are held to (see walk_kernel)
 
 #ifdef RT_ABLATION
 // Experiment builds only (tools/wave_trace.py): per wave of the last walk launch, 100 MHz clock at its first queue pop,
@@ -231,11 +232,14 @@ __device__ __forceinline__ void store_chunk_wave(const AccWave& acc, const unsig
 //   PLAIN (with a Fixed V) also fixes the reference's defaults rand_mu = 0 and monochromatic = 0 at compile time: the
 //                 selects they cost per emission, and the scalar registers their operands occupy, go away.
 //
-// The lean kernels of the re-emitting boundary are held to 5 waves per SIMD (96 vector registers; their depth-bin forms
-// spill 3 to 5 dwords for it): the two dependent gathers of a re-emission sit in the middle of the flight with nothing
-// of the wave's own to run under them, so they are the kernels that gain from one more resident wave (+2 ... +5 %).
+// The lean kernels other than the production configuration's are held to 5 waves per SIMD (96 vector registers).  Left alone the compiler takes 97-117 for those
+// with depth bins, the re-emitting boundary, the shell or the exact Draine law, and one wave fewer; told to, it fits the
+// depth-bin kernels without a spill (+3 ... +4 %) and the others with 3 to 18 spilled dwords outside the hot blocks
+// (+0 ... +5 %; the re-emitting ones gain most: the two dependent gathers of a re-emission sit in the middle of the
+// flight with nothing of the wave's own to run under them).  The production configuration is left alone: its kernels
+// need 87-99 registers and none of them spills.
 template <class V, int RNG, bool PLAIN>
-__global__ __launch_bounds__(kWalkBlock, (V::kFixed && V::kReemit) ? 5 : 1) void walk_kernel(const Cfg cfg0, const Sweep sw,
+__global__ __launch_bounds__(kWalkBlock, (V::kFixed && !std::is_same<V, FixedBase>::value) ? kHeldWaves : 1) void walk_kernel(const Cfg cfg0, const Sweep sw,
                                                            unsigned int* __restrict__ d_next,
                                                            double* __restrict__ d_chunk_sums,
                                                            unsigned long long* __restrict__ d_counts,
