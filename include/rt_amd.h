@@ -277,8 +277,13 @@ int rt_run_device(rt_ctx* ctx, const rt_params* p, void* d_slab_sums, void* d_co
  * many as fit, at most 64) and 80 + 16 * n_depth_bins bytes per chunk of this rank's slabs (a chunk is 8192 photon ids
  * for slabs of at least 250 000 ids, shorter below) <= 33554432 bytes in all -- the headline sweep (100 atmospheres x 2e7 photons on
  * one GPU: 244 800 chunks) needs 21 MB of it.  rt_set_tables must have been called before (that call allocates).
- * All contexts of one GPU share the array: two static sweeps in flight on one GPU at the same time, on whatever
- * streams or contexts, race; successive calls on one stream are ordered and need no clearing by the caller. */
+ * All contexts of one GPU share the array, and it keeps the last call's contents: the call clears what must start at
+ * zero, and the library orders the static sweeps of a GPU among themselves -- a call that goes to another stream than
+ * the GPU's previous static sweep makes its stream wait (hipStreamWaitEvent, on the device, no allocation) for that
+ * sweep's last kernel, so static sweeps from different streams or contexts of one process take turns on the array
+ * instead of racing, in the order of the calls.  What the library cannot see still races: the array is per process
+ * and per GPU, but a caller that enqueues static sweeps of ONE context from two host threads at once, or frees a
+ * result buffer while a sweep is in flight, is on its own (contexts are not thread-safe). */
 int rt_run_device_static(rt_ctx* ctx, const rt_params* p, void* d_slab_sums, void* d_counts, void* d_mu_hist,
                          void* d_slab_depth, void* stream);
 

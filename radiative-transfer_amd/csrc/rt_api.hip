@@ -11,6 +11,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <numeric>
 #include <string>
 #include <vector>
@@ -66,11 +67,24 @@ struct EventPair {
 // Work memory of rt_run_device_static: callers that cannot allocate (HIP graph capture, tight serving loops) get the
 // sweep's queue, plan and chunk partial sums from this array instead of hipMalloc.  Every GPU the library runs on
 // holds its own copy until the process ends; host code never uses the array's name as an address, only the
-// per-device pointer hipGetSymbolAddress returns (rt_create).  All calls on one GPU share it: calls that overlap
-// on one GPU race.
+// per-device pointer hipGetSymbolAddress returns (rt_create).  All calls on one GPU share it; the library orders them
+// (g_static_last below), so that calls from different streams or contexts take turns instead of racing.
 constexpr size_t kStaticScratchBytes = (size_t)32 << 20;
 constexpr int kStaticMaxAtm = 4096;
 static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
+
+// The static work array of a GPU serves one sweep at a time.  Static sweeps enqueued on different streams (or from
+// different contexts) of one GPU are therefore ordered by the library itself: every static sweep records an event
+// behind its last kernel, and the next one on that GPU, if it goes to another stream, makes its stream wait for that
+// event before its plan upload.  Neither operation allocates.  g_static_mutex also covers the enqueue itself, so that
+// the order of the events is the order of the uploads.
+constexpr int kMaxDevices = 64;
+struct StaticLast {
+    hipEvent_t done = nullptr;     // owned by the context that enqueued the sweep
+    hipStream_t stream = nullptr;
+};
+static StaticLast g_static_last[kMaxDevices];
+static std::mutex g_static_mutex;
 
 struct rt_ctx {
     int device = 0;
@@ -94,6 +108,7 @@ struct rt_ctx {
     size_t h_stage_bytes = 0;
     hipEvent_t staged = nullptr;
     bool staged_pending = false;
+    hipEvent_t static_done = nullptr;  // recorded behind this context's latest static sweep (see g_static_last)
     // result staging for rt_run / rt_replay
     DevBuf<double> d_slab_sums, d_depth, d_sums;  // d_depth: [n_atm][n_slabs][2][n_depth_bins] (rt_run), [2][n_depth_bins] (rt_replay)
     DevBuf<unsigned long long> d_counts, d_mu_hist;
@@ -320,6 +335,8 @@ int enqueue_sweep(rt_ctx* ctx, const rt_params* p, void* d_slab_sums, void* d_co
     const int world = p->world > 0 ? p->world : 1;
     if (p->rank < 0 || p->rank >= world) return fail(RT_ERR_INVALID, "rank %d not in [0,%d)", p->rank, world);
     if (n_slabs % world != 0) return fail(RT_ERR_INVALID, "n_slabs (%d) must be a multiple of world (%d)", n_slabs, world);
+    if (use_static && ctx->device >= kMaxDevices)
+        return fail(RT_ERR_LIMIT, "rt_run_device_static serves device ids below %d (this context is on %d)", kMaxDevices, ctx->device);
     if (use_static && p->n_atm > kStaticMaxAtm)
         return fail(RT_ERR_LIMIT, "rt_run_device_static takes at most %d atmospheres per call (got %d)", kStaticMaxAtm, p->n_atm);
     RT_HIP(hipSetDevice(ctx->device));
@@ -479,6 +496,12 @@ int enqueue_sweep(rt_ctx* ctx, const rt_params* p, void* d_slab_sums, void* d_co
     }
 
     // ---- device work: one upload, one kernel that zeroes what the walk accumulates into, the walk, slab sums and tally fold
+    std::unique_lock<std::mutex> static_lock;
+    if (use_static) {  // the GPU's static array is free once the previous static sweep's last kernel has run
+        static_lock = std::unique_lock<std::mutex>(g_static_mutex);
+        const StaticLast& last = g_static_last[ctx->device];
+        if (last.done && last.stream != stream) RT_HIP(hipStreamWaitEvent(stream, last.done, 0));
+    }
     RT_HIP(hipMemcpyAsync(work, ctx->h_stage, lay.upload_bytes, hipMemcpyHostToDevice, stream));
     RT_HIP(hipEventRecord(ctx->staged, stream));
     ctx->staged_pending = true;
@@ -494,6 +517,11 @@ int enqueue_sweep(rt_ctx* ctx, const rt_params* p, void* d_slab_sums, void* d_co
     RT_HIP(rt::launch_finish(sw, d_chunk_sums, (double*)d_slab_sums, d_count_copies, (unsigned long long*)d_counts,
                              na * RT_NCNT, d_hist_copies, (unsigned long long*)d_mu_hist, na * nmu, d_chunk_depth,
                              (double*)d_depth, p->n_depth_bins, stream));
+    if (use_static) {
+        RT_HIP(hipEventRecord(ctx->static_done, stream));
+        g_static_last[ctx->device].done = ctx->static_done;
+        g_static_last[ctx->device].stream = stream;
+    }
     return RT_OK;
 }
 
@@ -530,7 +558,9 @@ int rt_create(rt_ctx** out, int device_id) {
     }
     e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->staged, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->static_done, hipEventDisableTiming);
     if (e != hipSuccess) {
+        if (ctx->staged) (void)hipEventDestroy(ctx->staged);
         if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
         delete ctx;
         return fail(RT_ERR_DEVICE, "hipStreamCreate / hipEventCreate: %s", hipGetErrorString(e));
@@ -589,6 +619,7 @@ int rt_destroy(rt_ctx* ctx) {
     if (!ctx) return RT_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->static_done) (void)hipEventSynchronize(ctx->static_done);  // its latest static sweep, on whatever stream
     (void)rt_comm_destroy(ctx);
     for (auto& e : ctx->events) {
         (void)hipEventDestroy(e.a);
@@ -602,6 +633,11 @@ int rt_destroy(rt_ctx* ctx) {
     ctx->d_escaped_mu.release();
     if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
     if (ctx->staged) (void)hipEventDestroy(ctx->staged);
+    if (ctx->static_done) {
+        std::lock_guard<std::mutex> lock(g_static_mutex);
+        if (ctx->device < kMaxDevices && g_static_last[ctx->device].done == ctx->static_done) g_static_last[ctx->device] = StaticLast();
+        (void)hipEventDestroy(ctx->static_done);
+    }
     ctx->d_slab_sums.release();
     ctx->d_depth.release();
     ctx->d_sums.release();

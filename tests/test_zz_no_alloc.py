@@ -99,3 +99,41 @@ def test_static_entry_point_leaves_device_memory_alone(rt):
     eng.run_device(big, slab.data_ptr(), counts.data_ptr(), hist.data_ptr(), None, stream, static=True)   # fits the array: 8.9 MB
     torch.cuda.synchronize()
     eng.close()
+
+
+def test_static_sweeps_from_two_streams_and_contexts_take_turns(rt):
+    """All static sweeps of a GPU share one work array.  Sweeps enqueued from two contexts on two streams, with no
+    host synchronisation and no event of the caller's between them, must still give the allocating entry point's
+    bits: the library makes each wait for the previous one's last kernel.  (A build without that wait passes this test
+    too on most runs: a walk launch fills every wave slot of the GPU, so the next sweep's first operations only get
+    onto the device while the last waves of the previous one retire, and the window in which they can hurt each other
+    is a few microseconds.  The test pins the results of the pattern, the ordering itself is by construction.)"""
+    import torch
+    A = rt._abi
+    dev = torch.device("cuda", 0)
+    engs = [rt.Engine(0), rt.Engine(0)]
+    for e in engs:
+        e.set_tables(*_tables())
+    # the first and third sweep run for milliseconds, the host needs tens of microseconds to enqueue the next one
+    cases = [(np.logspace(-1, 1.3, 12), 20000000, 0), (np.array([0.05, 2.0, 20.0, 7.0]), 90001, 1),
+             (np.logspace(-2, 1.0, 30), 6000000, 2), (np.array([5.0]), 1200000, 3)]
+    want = [_run(rt, engs[0], torch, tau, n, static=False, seed=7 + s) for tau, n, s in cases]
+    streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+    outs = []
+    for rep in range(3):
+        for k, (tau, n, s) in enumerate(cases):
+            prm = rt.make_params(tau, n, n_mu_bins=10, seed=7 + s)
+            slab = torch.full((prm.n_atm * 8 * A.NSUM,), 7.0, dtype=torch.float64, device=dev)
+            counts = torch.full((prm.n_atm * A.NCNT,), 7, dtype=torch.int64, device=dev)
+            hist = torch.full((prm.n_atm * 11,), 7, dtype=torch.int64, device=dev)
+            outs.append((k, slab, counts, hist))
+            # alternate context and stream; the long first case is still running when the next one is enqueued
+            engs[(k + rep) % 2].run_device(prm, slab.data_ptr(), counts.data_ptr(), hist.data_ptr(), None,
+                                           streams[k % 2].cuda_stream, static=True)
+    torch.cuda.synchronize()
+    for k, slab, counts, hist in outs:
+        assert np.array_equal(slab.cpu().numpy(), want[k][0])
+        assert np.array_equal(counts.cpu().numpy(), want[k][1])
+        assert np.array_equal(hist.cpu().numpy(), want[k][2])
+    for e in engs:
+        e.close()
