@@ -62,6 +62,7 @@ __global__ __launch_bounds__(64) void finish_kernel(const Sweep sw, const double
         if (slab % sw.world == sw.rank) {
             const unsigned int j = slab / sw.world;
             const double* src = d_chunk_depth + ((size_t)plan.slot_base + (size_t)j * plan.chunks) * (2u * n_depth) + entry;
+#pragma unroll 8  // loads of eight chunks in flight; the additions stay in chunk order
             for (unsigned int c = 0; c < plan.chunks; ++c) s += src[(size_t)c * (2u * n_depth)];
         }
         d_slab_depth[((size_t)plan.atm * sw.n_slabs + slab) * (2u * n_depth) + entry] = s;
@@ -75,6 +76,7 @@ __global__ __launch_bounds__(64) void finish_kernel(const Sweep sw, const double
         if (j >= n) return;
         const unsigned long long* in = is_count ? d_count_copies : d_hist_copies;
         unsigned long long s = 0ull;
+#pragma unroll 8  // eight independent loads in flight per lane instead of one (the copies are 8 n bytes apart)
         for (uint32_t c = 0; c < sw.n_copies; ++c) s += in[(size_t)c * n + j];
         (is_count ? d_counts : d_mu_hist)[j] = s;
         return;
