@@ -358,12 +358,13 @@ __device__ __forceinline__ void set_constants(const Cfg& cfg, double tau, const 
 }
 
 // BUF: alias entry and record through raw buffer loads (32-bit offsets), as the lean kernels' own emission.
-template <class V = Runtime, bool BUF = false>
+// PLAIN: rand_mu and monochromatic are known to be off (the kernel was chosen for that).
+template <class V = Runtime, bool BUF = false, bool PLAIN = false>
 __device__ __forceinline__ void emit_from_table(const Cfg& cfg, double tau, PhiloxSrc& src, Photon& ph) {
     double ua, ub;
     src.emit_pair(ua, ub);
     int i;
-    if (BUF && cfg.mono_index < 0) {  // sample_index() with the entry gathered by offset
+    if (BUF && (PLAIN || cfg.mono_index < 0)) {  // sample_index() with the entry gathered by offset
         const double x = ua * (double)cfg.n_wl;
         int b = (int)x;
         b = b < cfg.n_wl ? b : cfg.n_wl - 1;
@@ -373,7 +374,7 @@ __device__ __forceinline__ void emit_from_table(const Cfg& cfg, double tau, Phil
         i = sample_index(cfg, ua);
     }
     const TableRec r = BUF ? load_record_buffer(cfg, i) : load_record(cfg, i);
-    set_constants<V>(cfg, tau, r, cfg.rand_mu ? ub : 1.0, ph);
+    set_constants<V>(cfg, tau, r, (!PLAIN && cfg.rand_mu) ? ub : 1.0, ph);
 }
 
 // LEAN: the quotient by the unscaled division sequence (the IEEE quotient for the normal operands that occur: 0 <= z <= zmax)

@@ -296,7 +296,7 @@ __global__ __launch_bounds__(kWalkBlock, (V::kFixed && !std::is_same<V, FixedBas
                 const double p0 = p.p0, e1 = p.e1, b = p.b, dep = p.dep;
                 const uint32_t n_it = p.iter;
                 const int ns = p.n_scatter;
-                emit_from_table<V, FAST>(cfg, tau, src, p);
+                emit_from_table<V, FAST, PLAIN>(cfg, tau, src, p);
                 p.p0 = p0;
                 p.e1 = e1;
                 p.b = b;
@@ -429,7 +429,8 @@ __global__ __launch_bounds__(kWalkBlock, (V::kFixed && !std::is_same<V, FixedBas
                                             (fate == RT_FATE_ESCAPED && (V::gray(cfg) || V::shell(cfg)));
                         cfg.escaped_mu[it.mu_base + (gid - cfg.id_base)] = logged ? ph.mu : __builtin_nan("");
                     }
-                    retire<PLAIN, V>(cfg, ph, fate, acc, hist);
+                    // (after a re-emission the photon's weight is the new wavelength's: its initial momentum is kept in ph.p0)
+                    retire<PLAIN && !V::kReemit, V>(cfg, ph, fate, acc, hist);
                     alive = false;
                 }
             }

@@ -207,10 +207,12 @@ def test_which_kernel_serves_which_flags(rt, engine):
     tau = np.array([0.5, 5.0])
     want = [(dict(), "<mc,reflect,hg,plain>"), (dict(rand_mu=1), "<mc,reflect,hg>"),
             (dict(rng="philox32x4"), "<mc,reflect,hg,philox32x4,plain>"), (dict(rng="philox32x4", rand_mu=1), "<mc,reflect,hg,philox32x4>"),
-            (dict(n_depth_bins=8), "<mc,reflect,hg,depth>"),
-            (dict(boundary="absorb"), "<mc,absorb,hg>"), (dict(boundary="reemit"), "<mc,reemit,hg>"),
+            (dict(n_depth_bins=8), "<mc,reflect,hg,depth,plain>"), (dict(n_depth_bins=8, rand_mu=1), "<mc,reflect,hg,depth>"),
+            (dict(boundary="absorb"), "<mc,absorb,hg,plain>"), (dict(boundary="reemit"), "<mc,reemit,hg,plain>"),
+            (dict(boundary="absorb", monochromatic=1.0), "<mc,absorb,hg>"), (dict(boundary="reemit", rand_mu=1), "<mc,reemit,hg>"),
+            (dict(boundary="reemit", n_depth_bins=8), "<mc,reemit,hg,depth,plain>"),
             (dict(scatter="iso"), "<mc,reflect,iso>"), (dict(order="gray", h=1.0), "<gray,reflect,hg>"),
-            (dict(boundary="absorb", n_depth_bins=8), "<mc,absorb,hg,depth>"),
+            (dict(boundary="absorb", n_depth_bins=8), "<mc,absorb,hg,depth,plain>"),
             (dict(order="gray", h=1.0, boundary="reemit", scatter="iso", n_depth_bins=4), "<gray,reemit,iso,depth>"),
             (dict(abs_only=1), "<mc,reflect,hg,abs_only>"), (dict(abs_only=1, n_depth_bins=8), "<mc,reflect,hg,depth,abs_only>"),
             (dict(geometry="shell", shell_inner=1.0), "<mc,reflect,hg,shell>"),
