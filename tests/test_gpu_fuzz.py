@@ -5,6 +5,8 @@ configurations -- boundary x scattering law x loop order x geometry x stream x b
 photon counts x id base x seed x iteration cap -- so that options meet in combinations nobody listed, in the
 kernels with flags fixed at compile time and (three cases in ten are sent there whatever their flags) in the run-time one alike.  Integer tallies exact, sums to 1e-12.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -12,7 +14,7 @@ from test_gpu_multi_table import tables3
 from test_gpu_walk import compare, small_table
 
 pytestmark = pytest.mark.gpu
-N_CASES = 256
+N_CASES = int(os.environ.get("RT_FUZZ_CASES", "256"))  # a larger number for an occasional long run
 
 
 def draw_case(k):
