@@ -14,15 +14,6 @@
 
 namespace rt {
 
-#ifdef RT_ABLATION
-__device__ unsigned long long g_wave_trace[8 * 8192];
-extern "C" int rt_debug_wave_trace(unsigned long long* out, int n_waves) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_trace), sizeof(unsigned long long) * 8 * (size_t)n_waves);
-}
-#else
-__device__ unsigned long long g_wave_trace[1];  // never written: Ablation::kWaveTrace is false
-#endif
-
 // Zeroes what a sweep accumulates into with atomics: the queue counter and the tally copies.
 __global__ void zero_results_kernel(unsigned int* __restrict__ d_next, unsigned long long* __restrict__ a, size_t na) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;

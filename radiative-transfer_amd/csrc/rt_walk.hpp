@@ -25,10 +25,12 @@ constexpr int kHeldWaves = 5;  // waves per SIMD the lean instantiations are hel
 
 #ifdef RT_ABLATION
 // Experiment builds only (tools/wave_trace.py): per wave of the last walk launch, 100 MHz clock at its first queue pop,
-// at the start of its last chunk and at its end, and the number of chunks it walked.
-extern __device__ unsigned long long g_wave_trace[8 * 8192];
+// at the start of its last chunk and at its end, and the number of chunks it walked.  One copy per translation unit
+// (device symbols do not link across them); rt_debug_wave_trace reads the copy of rt_walk_base.hip, where the
+// production configuration's kernels are.
+[[maybe_unused]] static __device__ unsigned long long g_wave_trace[8 * 8192];
 #else
-extern __device__ unsigned long long g_wave_trace[1];  // never written: Ablation::kWaveTrace is false
+[[maybe_unused]] static __device__ unsigned long long g_wave_trace[1];  // never written: Ablation::kWaveTrace is false
 #endif
 
 __device__ __forceinline__ double wave_sum(double v) {

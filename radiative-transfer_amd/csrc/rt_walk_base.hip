@@ -5,6 +5,12 @@
 
 namespace rt {
 
+#ifdef RT_ABLATION
+extern "C" int rt_debug_wave_trace(unsigned long long* out, int n_waves) {  // tools/wave_trace.py
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_trace), sizeof(unsigned long long) * 8 * (size_t)n_waves);
+}
+#endif
+
 void register_walk_base(std::vector<WalkVariantInfo>& out) {
     add_walk_variant<Runtime, RT_RNG_PHILOX52, false>(out);    // kWalkRuntime
     add_walk_variant<Runtime, RT_RNG_PHILOX32X4, false>(out);  // kWalkRuntime + RT_RNG_PHILOX32X4
