@@ -1,7 +1,9 @@
 """The device table builder (rt_build_grain_tables) against the host NumPy builder, which the CPU tests pin to
 the reference's own CSV outputs (tests/test_tables.py).  Interpolation and the size integrals follow NumPy's
-operation order, so the per-wavelength columns agree to rounding; tolerance 1e-13 relative."""
+operation order, so the per-wavelength columns agree to rounding; tolerance 1e-13 relative.  The last test compares
+the device-built frame with the reference's own directly."""
 import importlib
+import os
 
 import numpy as np
 import pytest
@@ -85,3 +87,16 @@ def test_l_edd_dataframe_on_device(engine):
     dev = tables.l_edd_dataframe(spectra, wl, engine=engine)
     for key in host:
         _close(dev[key], host[key], 1e-12)
+
+
+@pytest.mark.parametrize("grain_type", ["mix", "Sil"])
+def test_device_built_frame_matches_the_reference_chain(engine, grain_type):
+    """g, Albedo, Scale built on the device against the frame the reference's unmodified GetGrainKappas chain returns
+    (tests/golden/grain_frame.npz, generator oracle/make_golden_grain_frame.py), with no host builder in between."""
+    from conftest import GOLDEN
+    z = np.load(os.path.join(GOLDEN, "grain_frame.npz"))
+    stride = int(z["wl_stride"])
+    wl = tables.reference_wavelength_grid()
+    gd = tables.grain_data(grain_type, 0.001, 1, wl, sed=tables.planck_sed(wl), engine=engine)
+    for col in ("Scale", "Kappa_RP", "Kappa_F", "ExtScale", "Albedo", "g"):
+        _close(np.asarray(gd[col])[::stride], z[f"{grain_type}/{col}"], rtol=3e-12)
