@@ -266,3 +266,51 @@ def runMC(BPASS_file, time_slice, num_photons, Range, Grain_data, momentum_metho
         save_mc_column(os.path.join(out_dir, mc_csv_name(grain_type, os.path.basename(str(BPASS_file)))), tau_list,
                        time_slice, momentum_transfer)
     return (momentum_transfer, res) if return_result else momentum_transfer
+
+
+def runMC_ages(time_slices, seds, num_photons, Range, Grain_data, photon_reduction=0, boundary="reflect", scatter="hg",
+               save_MC=False, *, BPASS_file="", tau_list=None, min_tau=10 ** -3, max_tau=100, grain_type="mix",
+               rand_mu=False, abs_only=False, h=H_PLANCK, seed=DEFAULT_SEED, out_dir=".", engine=None,
+               return_result=False):
+    """runMC (MC code.py:992-1073) for several stellar ages in ONE launch.
+
+    The reference builds its 'detailed MC ...csv' table one age at a time: one runMC call -- one Python loop over the
+    optical depths -- per column (MC code.py:1069-1071).  The ages share the grain tables and differ only in the
+    spectrum the wavelengths are drawn from, so here every (age, optical depth) pair is one atmosphere of a single
+    sweep: the emission law of age k is table k, its g / Albedo / Scale rows are the same rows again.  A sweep of
+    100 optical depths x 1e5 photons is too short to fill the GPU; thirteen or fifty-one of them in one launch are not.
+
+    time_slices: the column names (log ages); seds[k]: luminosity per unit wavelength of age k on `Range` (microns).
+    Returns {str(time_slice): momentum_transfer over tau_list}; with save_MC the columns are written to the
+    reference's CSV (created or extended, other columns kept).  Unlike successive runMC calls, which would give every
+    age the same random streams, every (age, optical depth) pair has streams of its own."""
+    eng = engine or default_engine()
+    tau_list = np.logspace(-3, 2, 100, base=10) if tau_list is None else np.asarray(tau_list, dtype=float)
+    tau_list_calc = tau_list[(tau_list >= min_tau) & (tau_list <= max_tau)]
+    n_ages, n_calc = len(time_slices), len(tau_list_calc)
+    if n_ages < 1 or len(seds) != n_ages:
+        raise ValueError("one spectrum per time slice is needed")
+    Range = np.asarray(Range, dtype=float)
+    pdfs = np.stack([tables.photon_pdf(Range, sed)[0] for sed in seds])
+    grain = {k: _column(Grain_data, k) for k in ("WL", "g", "Albedo", "Scale")}
+    wl, g, alb, sc = tables.join_on_wavelength(Range, grain)
+    missing = np.isnan(g)[None, :] & (pdfs > 0)
+    if missing.any():
+        raise ValueError(f"{int(missing.any(axis=0).sum())} wavelengths with non-zero emission probability have no entry in "
+                         "Grain_data.WL (the reference would loop forever on their NaN constants)")
+    pdfs[:, np.isnan(g)] = 0.0
+    rows = lambda a: np.broadcast_to(np.nan_to_num(a), (n_ages, len(wl)))
+    eng.set_tables(wl, rows(g), rows(alb), rows(sc), pdfs)
+    counts = photon_reduction_counts(num_photons, photon_reduction, n_calc)
+    prm = make_params(np.tile(tau_list_calc, n_ages), np.tile(counts, n_ages), boundary=boundary, scatter=scatter,
+                      rand_mu=int(bool(rand_mu)), abs_only=int(bool(abs_only)), seed=seed, h=h,
+                      table_of_atm=np.repeat(np.arange(n_ages), n_calc))
+    res = eng.run(prm)
+    method_1 = res.momentum_fraction().reshape(n_ages, n_calc)        # MC code.py:1062, one row per age
+    out = {}
+    for k, time_slice in enumerate(time_slices):
+        out[str(time_slice)] = extrapolate(tau_list, tau_list_calc, method_1[k], min_tau, max_tau)
+        if save_MC:
+            save_mc_column(os.path.join(out_dir, mc_csv_name(grain_type, os.path.basename(str(BPASS_file)))), tau_list,
+                           time_slice, out[str(time_slice)])
+    return (out, res) if return_result else out
